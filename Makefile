@@ -1,0 +1,52 @@
+# Build of the native pieces.  Everything is compiled with -ffp-contract=off:
+# the oracle (gcc) and the gfx950 kernels (hipcc) must round every expression
+# at the same place (DESIGN.md "Numerical contract").
+#
+#   make host     -> mort_amd/lib/libmort_host.so   (C scene layer, no GPU)
+#   make hip      -> mort_amd/lib/libmort_hip.so    (C-ABI + gfx950 kernels)
+#   make oracle   -> oracle/libmort_oracle.so       (CPU checker, test-only)
+#   make cli      -> mort_amd/bin/mort              (the `mort <scene_id>` CLI)
+#   make all
+
+ROCM ?= /opt/rocm
+HIPCC ?= $(ROCM)/bin/hipcc
+CC ?= gcc
+ARCH ?= gfx950
+
+LIBDIR := mort_amd/lib
+BINDIR := mort_amd/bin
+INC := -Iinclude
+
+CFLAGS := -O2 -std=gnu11 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math $(INC)
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
+            -fno-gpu-rdc -Wall -Wno-unused-parameter -Wno-unused-value -Wno-unused-result $(INC)
+
+HOST_SRC := mort_amd/csrc/host/mort_host.c mort_amd/csrc/host/mort_scenes.c
+HIP_SRC := $(wildcard mort_amd/csrc/hip/*.hip)
+HIP_HDR := $(wildcard mort_amd/csrc/hip/*.h) $(wildcard include/*.h)
+
+.PHONY: all host hip oracle cli clean
+all: host oracle hip cli
+
+host: $(LIBDIR)/libmort_host.so
+$(LIBDIR)/libmort_host.so: $(HOST_SRC) $(wildcard include/*.h) mort_amd/csrc/host/mort_vec.h
+	@mkdir -p $(LIBDIR)
+	$(CC) $(CFLAGS) -shared -o $@ $(HOST_SRC) -lm
+
+hip: $(LIBDIR)/libmort_hip.so
+$(LIBDIR)/libmort_hip.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+oracle:
+	$(MAKE) -C oracle
+
+cli: $(BINDIR)/mort
+$(BINDIR)/mort: mort_amd/csrc/cli/mort.c $(LIBDIR)/libmort_host.so $(LIBDIR)/libmort_hip.so
+	@mkdir -p $(BINDIR)
+	$(CC) $(CFLAGS) -fPIE -o $@ mort_amd/csrc/cli/mort.c -L$(LIBDIR) -lmort_host -lmort_hip \
+	    -Wl,-rpath,'$$ORIGIN/../lib' -lm -lpthread
+
+clean:
+	rm -rf $(LIBDIR) $(BINDIR)
+	$(MAKE) -C oracle clean

@@ -1,0 +1,120 @@
+/*
+ * mort_hip.h -- C ABI of libmort_hip.so, the MI355X (gfx950) render path.
+ *
+ * The reference has no plugin / FFI interface: host and device share one
+ * translation unit and the boundary is a kernel launch with by-value structs.
+ * The entry points below are what a binding for that boundary has to replace:
+ *
+ *   mort_hip_upload_world   <- world::toDevice()            world.cuh:98-102
+ *                              (16x cudaMemcpyToSymbol:     objects.cuh:848-856,
+ *                               materials.cuh:264-270, textures.cuh:320-325,
+ *                               image upload textures.cuh:89-127)
+ *   mort_hip_rng_seed       <- setup_rng<<<>>>              rng.cuh:8-15, mort.cu:706-709
+ *   mort_hip_rng_load/store <- (dev_states array itself)    mort.cu:706-708
+ *   mort_hip_render[_device]<- renderKernel<<<>>> + the four per-bounce scratch
+ *                              allocations                  mort.cu:44-47,106,712-725
+ *   mort_hip_init/shutdown  <- implicit device 0 context    textures.cuh:91
+ *
+ * Conventions: plain C, no C++ types or exceptions cross the boundary.  The
+ * caller owns every host buffer; the library owns all device memory behind
+ * the opaque mort_ctx (except buffers passed to mort_hip_render_device).
+ * Calls are blocking unless stated; one context per process per device; a
+ * context is not re-entrant.  Every function returns MORT_OK (0) or a
+ * negative mort_status; the reference's convention is print-and-exit
+ * (HANDLE_ERROR, include/book.h:21-30), which the `mort` CLI reproduces on
+ * top of these codes.
+ */
+#ifndef MORT_HIP_H
+#define MORT_HIP_H
+
+#include "mort_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mort_ctx mort_ctx;
+
+typedef enum mort_status {
+    MORT_OK = 0,
+    MORT_ERR_INVALID = -1,      /* NULL / out-of-range argument */
+    MORT_ERR_NO_DEVICE = -2,    /* no HIP device, or not gfx950 */
+    MORT_ERR_HIP = -3,          /* a HIP runtime call failed (see mort_hip_last_error) */
+    MORT_ERR_NO_WORLD = -4,     /* render before upload_world */
+    MORT_ERR_NO_RNG = -5,       /* render before rng_seed / rng_load */
+    MORT_ERR_UNSUPPORTED = -6,  /* scene graph outside what the kernels flatten */
+    MORT_ERR_CAPACITY = -7,     /* bounce_limit > MORT_MAX_BOUNCE_LIMIT, nesting too deep, ... */
+    MORT_ERR_NOMEM = -8
+} mort_status;
+
+/* render modes */
+#define MORT_MODE_MEGA 0 /* one lane per pixel, whole path on chip */
+#define MORT_MODE_WAVE 1 /* wavefront (queued) pipeline; not built yet: returns MORT_ERR_UNSUPPORTED */
+
+/* Which rows of the image this context renders: rows are grouped into blocks
+ * of `rows_per_block` and this context owns blocks rank, rank+nranks, ...
+ * (image-space partition across GPUs).  {0,1,8} = whole image. */
+typedef struct mort_partition {
+    int rank;
+    int nranks;
+    int rows_per_block; /* multiple of 8 */
+} mort_partition;
+
+typedef struct mort_stats {
+    double seconds;          /* device time of the render kernel(s), HIP events */
+    uint64_t segments;       /* world::hit calls == path segments traced */
+    uint64_t pixels;         /* pixels rendered by this context */
+    uint64_t eff_samples;    /* pixels * floor(sqrt(spp))^2 */
+    uint64_t rng_draws;      /* curand_uniform calls */
+    uint64_t algorithmic_hbm_bytes; /* 100 B/pixel (+12 with accum) */
+    int scene_in_lds;        /* 1 if the kernel staged the scene in LDS */
+    int local_rows;          /* rows owned under the partition */
+    int kernel_vgprs, kernel_lds_bytes; /* launch facts, for reports */
+} mort_stats;
+
+const char *mort_hip_strerror(int status);
+/* Text of the last HIP error seen by this context ("" if none). */
+const char *mort_hip_last_error(const mort_ctx *ctx);
+
+/* device = HIP ordinal (one process per GPU uses LOCAL_RANK). */
+int mort_hip_init(int device, mort_ctx **out);
+void mort_hip_shutdown(mort_ctx *ctx);
+
+/* Copies and re-lays-out the world for the kernels; the caller keeps ownership
+ * of every host array (including image texels) and may free them afterwards. */
+int mort_hip_upload_world(mort_ctx *ctx, const mort_world *world);
+
+int mort_hip_set_partition(mort_ctx *ctx, const mort_partition *part);
+
+/* states[x + y*W] = curand_init(seed, subsequence = x + y*W, offset = 0) for
+ * every pixel this context owns (unlike rng.cuh:8-15, bounds-guarded). */
+int mort_hip_rng_seed(mort_ctx *ctx, uint64_t seed, int width, int height);
+/* Full-image arrays of W*H 48-byte curandStateXORWOW records, row-major from
+ * the bottom row (the reference's layout); only owned rows are read/written. */
+int mort_hip_rng_load(mort_ctx *ctx, const mort_rng_state *states, int width, int height);
+int mort_hip_rng_store(mort_ctx *ctx, mort_rng_state *states, int width, int height);
+
+/* Renders the owned rows into full-size host buffers: rgba_out W*H*4 bytes
+ * (uchar4, row 0 = bottom row, as the reference's GL buffer), accum_out W*H*3
+ * floats (linear pixel mean before gamma) or NULL, segments_px_out W*H
+ * uint32 or NULL.  Rows not owned are left untouched. */
+int mort_hip_render(mort_ctx *ctx, const mort_camera *cam, int mode, uint8_t *rgba_out, float *accum_out,
+                    uint32_t *segments_px_out, mort_stats *stats);
+
+/* Same render into caller-provided DEVICE buffers holding only the owned rows,
+ * packed (local_rows * W pixels): d_rgba local_rows*W*4 bytes, d_accum
+ * local_rows*W*3 floats or NULL.  Launched on `stream` (a hipStream_t, NULL =
+ * the context's stream); asynchronous when stats is NULL, otherwise waits and
+ * fills stats.  This is the entry bench.py and the multi-GPU gather use. */
+int mort_hip_render_device(mort_ctx *ctx, const mort_camera *cam, int mode, void *d_rgba, void *d_accum,
+                           void *stream, mort_stats *stats);
+
+/* Number of rows owned for an image of `height` rows under the current partition. */
+int mort_hip_local_rows(const mort_ctx *ctx, int height);
+/* Global row index of local row `local_row`. */
+int mort_hip_global_row(const mort_ctx *ctx, int local_row);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MORT_HIP_H */

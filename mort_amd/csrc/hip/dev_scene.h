@@ -1,0 +1,101 @@
+/*
+ * dev_scene.h -- the scene as the gfx950 kernels see it.
+ *
+ * mort_hip_upload_world() "compiles" the reference's tagged object graph
+ * (world.cuh:104-171 walks it with switch dispatch and recursion) into flat,
+ * 16-byte-aligned arrays sized for LDS staging:
+ *
+ *   - the closest-hit sequence of world::hit becomes a list of ITEMS in the
+ *     reference's visiting order (BVHs, then spheres, quads, translates,
+ *     rotate_ys, constant_mediums, lists; world.cuh:110-168); nested
+ *     translate / rotate_y / hittable_list objects are flattened into runs of
+ *     primitives that share a transform CHAIN;
+ *   - each BVH (objects.cuh:725-735, SoA with child type/index arrays) becomes
+ *     a threaded pre-order array: a box hit moves to node+1, a miss (or a
+ *     finished leaf) to node.skip, which reproduces the reference's left-first
+ *     stack walk (objects.cuh:664-723) without a stack;
+ *   - primitives keep only the fields hit/pdf/random read.
+ */
+#ifndef MORT_DEV_SCENE_H
+#define MORT_DEV_SCENE_H
+
+#include <stdint.h>
+#include "mort_scene.h"
+
+/* material / texture references: (type << 16) | idx */
+#define DREF(type, idx) (((uint32_t)(type) << 16) | (uint32_t)(idx))
+#define DREF_TYPE(r) ((int)((r) >> 16) & 0x7fff)
+#define DREF_IDX(r) ((int)((r) & 0xffffu))
+
+struct __attribute__((aligned(16))) DSphere { /* 32 B */
+    float cx, cy, cz, radius;
+    float vx, vy, vz;   /* center_vec (0 when !moves) */
+    uint32_t mat;       /* DREF | moves << 31 */
+};
+
+struct __attribute__((aligned(16))) DQuad { /* 80 B */
+    float Q[3], D;
+    float u[3], area;
+    float v[3]; uint32_t mat;
+    float n[3]; uint32_t pad0;
+    float w[3]; uint32_t pad1;
+};
+
+/* threaded BVH node, pre-order; 32 B */
+struct __attribute__((aligned(16))) DBvhNode {
+    float xmin, xmax, ymin, ymax, zmin, zmax;
+    uint32_t skip;  /* next node when this subtree is done/missed; bit 31 = leaf */
+    uint32_t prims; /* leaf: primA | primB << 16; prim = kind << 15 | index (kind 0 sphere, 1 quad) */
+};
+
+enum { XF_TRANSLATE = 0, XF_ROTATE_Y = 1 };
+struct __attribute__((aligned(16))) DXform { /* 16 B */
+    int kind;
+    float a, b, c; /* translate: offset xyz; rotate_y: sin, cos, - */
+};
+
+enum { ITEM_BVH = 0, ITEM_SPHERES = 1, ITEM_QUADS = 2, ITEM_MEDIUM = 3 };
+struct __attribute__((aligned(16))) DItem { /* 32 B */
+    int kind;
+    int first, count;          /* BVH: node range; prims: range in dev arrays; medium: sub-item range */
+    int chain_first, chain_count;
+    uint32_t mat;              /* medium: phase-function material */
+    int medium;                /* medium: index into neg_inv_density[] */
+    int pad;
+};
+
+struct __attribute__((aligned(16))) DLambert { float r, g, b; uint32_t tex; }; /* tex != 0: look up, else rgb inline */
+struct __attribute__((aligned(16))) DMetal { float r, g, b, fuzz; };
+struct __attribute__((aligned(8))) DDielectric { float ior, inv_ior; };
+struct __attribute__((aligned(16))) DSolid { float r, g, b, pad; };
+struct __attribute__((aligned(16))) DChecker { float inv_scale; uint32_t even, odd; uint32_t pad; };
+struct __attribute__((aligned(16))) DImage { uint32_t offset; int width, height, pad; }; /* offset into texels */
+
+/* light object for hittable_pdf (pdf.cuh:60-80): a flattened list of
+ * sphere / quad primitives, or "none of those" (value 0, direction (1,0,0)). */
+enum { LIGHT_NONE = -1, LIGHT_INVALID = 0, LIGHT_SPHERE = 1, LIGHT_QUAD = 2, LIGHT_LIST = 3 };
+
+/* All pointers are device addresses inside one allocation. */
+struct DScene {
+    const DItem *items;     int n_items;      /* world-level sequence */
+    const DItem *subitems;  int n_subitems;   /* medium boundaries */
+    const DBvhNode *nodes;  int n_nodes;
+    const DSphere *spheres; int n_spheres;
+    const DQuad *quads;     int n_quads;
+    const DXform *xforms;   int n_xforms;
+    const double *neg_inv_density; int n_media;
+    const DLambert *lambert; const DMetal *metal; const DDielectric *dielectric;
+    const DLambert *dlight;  const DLambert *isotropic; /* {rgb | tex} like lambertian */
+    const DSolid *solid; const DChecker *checker; const DImage *image;
+    const unsigned char *texels;
+    const float *noise;     /* mort_noise_texture records, 6152 B each */
+    /* light sampling reads objects by their WORLD index (camera.light_obj_*):
+     * world-order copies of every sphere / quad and of the hittable lists */
+    const DSphere *wspheres; const DQuad *wquads;
+    const int *list_types; const int *list_idxs; /* concatenated */
+    int list_first[MORT_NUM_HITTABLE_LIST]; int list_count[MORT_NUM_HITTABLE_LIST];
+    uint32_t blob_bytes;    /* size of everything above texels/noise (LDS staging candidate) */
+    uint32_t lds_bytes;     /* bytes the staged part needs */
+};
+
+#endif

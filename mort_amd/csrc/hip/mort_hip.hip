@@ -1,0 +1,756 @@
+/*
+ * mort_hip.hip -- libmort_hip.so: the C ABI of include/mort_hip.h and the
+ * gfx950 kernels behind it.
+ *
+ * Kernels (hand-written for CDNA4, wave64):
+ *   seed_kernel   per-pixel XORWOW init with the 2^67-step sequence skip
+ *                 (replaces setup_rng, rng.cuh:8-15)
+ *   mega_kernel   one lane per pixel, 8x8 pixel tile per wave; the whole
+ *                 sample x bounce nest of Camera::render / ray_color
+ *                 (camera.cuh:86-208) runs as ONE flat per-lane loop so that a
+ *                 lane whose path ends starts its next sample immediately
+ *                 instead of idling until the longest path of the wave ends.
+ *                 RNG state in 6 VGPRs for the pixel's lifetime; bounce stack
+ *                 private; no global scratch arrays (mort.cu:712-725).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "mort_hip.h"
+#include "dev_trace.h"
+#include "scene_compile.h"
+
+#pragma clang fp contract(off)
+
+/* ====================================================================== device */
+
+struct RenderArgs {
+    DScene sc;
+    /* camera (camera.cuh:13-45) */
+    int width, height;
+    int sqrt_spp, bounce_limit;
+    float recip_sqrt_spp, pixel_samples_scale;
+    V3 background, center, pixel00, du, dv, defocus_u, defocus_v;
+    float defocus_angle;
+    int light_type, light_idx;
+    /* partition: this launch owns row blocks rank, rank + nranks, ... */
+    int rank, nranks, rows_per_block, local_rows;
+    /* buffers (packed owned rows) */
+    mort_rng_state *states;
+    uchar4 *rgba;
+    float *accum;          /* may be null */
+    uint32_t *seg_px;      /* may be null */
+    unsigned long long *counters; /* [0] segments, [1] rng draws */
+};
+
+DEV int global_row(int ly, int rank, int nranks, int rpb) {
+    const int lb = ly / rpb, within = ly - lb * rpb;
+    return (lb * nranks + rank) * rpb + within;
+}
+
+/* ---- Camera::get_ray (camera.cuh:210-242) ---- */
+DEV Ray get_ray(const RenderArgs &a, int x, int y, Rng &rng, int s_i, int s_j) {
+    const double px = (double)(((float)s_i + random_float(rng)) * a.recip_sqrt_spp) - 0.5;
+    const double py = (double)(((float)s_j + random_float(rng)) * a.recip_sqrt_spp) - 0.5;
+    const float ox = (float)px, oy = (float)py;
+    const V3 pixel_sample = vadd(vadd(a.pixel00, vscale((float)((double)x + (double)ox), a.du)),
+                                 vscale((float)((double)y + (double)oy), a.dv));
+    V3 origin;
+    if (a.defocus_angle <= 0) {
+        origin = a.center;
+    } else {
+        const V3 p = random_in_unit_disk(rng);
+        origin = vadd(vadd(a.center, vscale(p.x, a.defocus_u)), vscale(p.y, a.defocus_v));
+    }
+    Ray r;
+    r.o = origin;
+    r.d = vsub(pixel_sample, origin);
+    r.tm = random_float(rng);
+    return r;
+}
+
+/* ---- light object sampling (pdf.cuh:60-80 over objects.cuh dispatchers) ---- */
+DEV float light_pdf_value(const DScene &sc, int type, int idx, V3 origin, V3 direction) {
+    if (type == MORT_OBJ_SPHERE) return wsphere_pdf_value(sc.wspheres[idx], origin, direction);
+    if (type == MORT_OBJ_QUAD) return wquad_pdf_value(sc.wquads[idx], origin, direction);
+    if (type == MORT_OBJ_HITTABLE_LIST) { /* objects.cuh:488-498 */
+        const int first = sc.list_first[idx], n = sc.list_count[idx];
+        const float weight = (float)(1.0 / (double)(float)n);
+        float sum = 0.0f;
+        for (int i = 0; i < n; i++) {
+            const int t = sc.list_types[first + i], k = sc.list_idxs[first + i];
+            float v = 0.0f;
+            if (t == MORT_OBJ_SPHERE) v = wsphere_pdf_value(sc.wspheres[k], origin, direction);
+            else if (t == MORT_OBJ_QUAD) v = wquad_pdf_value(sc.wquads[k], origin, direction);
+            sum += weight * v;
+        }
+        return sum;
+    }
+    return 0.0f; /* pdfValueDispatch default (objects.cuh:961) */
+}
+DEV V3 light_random(const DScene &sc, int type, int idx, V3 origin, Rng &rng) {
+    if (type == MORT_OBJ_HITTABLE_LIST) { /* objects.cuh:500-504 */
+        const int first = sc.list_first[idx], n = sc.list_count[idx];
+        const int k = random_int(rng, 0, n - 1);
+        type = sc.list_types[first + k];
+        idx = sc.list_idxs[first + k];
+        if (type == MORT_OBJ_HITTABLE_LIST) return mk(1, 0, 0); /* nested lists are rejected on the host */
+    }
+    if (type == MORT_OBJ_SPHERE) return wsphere_random(sc.wspheres[idx], origin, rng);
+    if (type == MORT_OBJ_QUAD) return wquad_random(sc.wquads[idx], origin, rng);
+    return mk(1, 0, 0); /* randomDispatch default (objects.cuh:978) */
+}
+
+/* one bounce-stack entry: k = scattering_pdf * attenuation, rp = 1 / pdf.
+ * The unwind (camera.cuh:166-173) computes emission + (1/pdf)*((spdf*att)*final);
+ * spdf*att and 1/pdf are the same fp32 values whenever they are formed, and the
+ * pushed emission is always (0,0,0): only diffuse_light emits and it never scatters. */
+struct StackEntry { float kx, ky, kz, rp; };
+
+extern "C" __global__ void __launch_bounds__(256)
+mega_kernel(const RenderArgs a) {
+    const DScene &sc = a.sc;
+    const int lane = threadIdx.x & 63;
+    const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int tiles_x = (a.width + 7) >> 3;
+    const int tx = wave % tiles_x, ty = wave / tiles_x;
+    const int x = tx * 8 + (lane & 7);
+    const int ly = ty * 8 + (lane >> 3);
+    const bool active = (x < a.width) && (ly < a.local_rows);
+    if (!active) return;
+
+    const int y = global_row(ly, a.rank, a.nranks, a.rows_per_block);
+    const int lofs = x + ly * a.width;
+
+    Rng rng;
+    {
+        const mort_rng_state st = a.states[lofs];
+        rng.d = st.d; rng.v0 = st.v[0]; rng.v1 = st.v[1]; rng.v2 = st.v[2]; rng.v3 = st.v[3]; rng.v4 = st.v[4];
+        rng.draws = 0;
+    }
+
+    StackEntry stack[MORT_MAX_BOUNCE_LIMIT];
+    V3 pixel_color = mk(0, 0, 0);
+    const int spp = a.sqrt_spp * a.sqrt_spp;
+    int s = 0, s_i = 0, s_j = 0;
+    int iter = 0;
+    bool fresh = true;
+    uint32_t segments = 0;
+    Ray ray;
+    float ray_time0 = 0.f;
+
+    while (s < spp) {
+        if (fresh) { /* camera.cuh:187-190 */
+            ray = get_ray(a, x, y, rng, s_i, s_j);
+            ray_time0 = ray.tm;
+            iter = 0;
+            fresh = false;
+        }
+        /* ---- one iteration of ray_color's bounce loop (camera.cuh:96-159) ---- */
+        V3 final_value;
+        bool done = false;
+        if (iter >= a.bounce_limit) {
+            final_value = mk(0, 0, 0);
+            done = true;
+        } else {
+            Best best;
+            segments++;
+            if (!world_hit(sc, ray, rng, best)) {
+                final_value = a.background;
+                done = true;
+            } else {
+                HitRec rec;
+                resolve_hit(sc, ray, best, rec);
+                const int mtype = DREF_TYPE(rec.mat), midx = DREF_IDX(rec.mat);
+                if (mtype == MORT_MAT_METAL) { /* materials.cuh:73-84 */
+                    const DMetal m = sc.metal[midx];
+                    V3 reflected = reflect(ray.d, rec.normal);
+                    reflected = vadd(vunit(reflected), vscale(m.fuzz, random_unit_vector(rng)));
+                    ray.o = rec.p; ray.d = reflected; /* time stays r_in.time() */
+                    StackEntry e; e.kx = 1.0f * m.r; e.ky = 1.0f * m.g; e.kz = 1.0f * m.b; e.rp = 1 / 1.0f;
+                    stack[iter] = e;
+                    iter++;
+                } else if (mtype == MORT_MAT_DIELECTRIC) { /* materials.cuh:107-130 */
+                    const DDielectric m = sc.dielectric[midx];
+                    const float refraction_ratio = rec.front_face ? m.inv_ior : m.ior;
+                    const V3 unit_direction = vunit(ray.d);
+                    const float cos_theta = (float)mort_fmin((double)vdot(vneg(unit_direction), rec.normal), 1.0);
+                    const float sin_theta = (float)mort_sqrt(1.0 - (double)(cos_theta * cos_theta));
+                    const bool cant_refract = (double)(refraction_ratio * sin_theta) > 1.0;
+                    V3 direction;
+                    if (cant_refract || reflectance(cos_theta, refraction_ratio) > random_float(rng))
+                        direction = reflect(unit_direction, rec.normal);
+                    else
+                        direction = refract(unit_direction, rec.normal, refraction_ratio);
+                    ray.o = rec.p; ray.d = direction;
+                    StackEntry e; e.kx = 1.0f; e.ky = 1.0f; e.kz = 1.0f; e.rp = 1.0f;
+                    stack[iter] = e;
+                    iter++;
+                } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
+                    /* materials.cuh:38-44,182-188 + camera.cuh:115-145 */
+                    const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
+                    const DLambert m = lamb ? sc.lambert[midx] : sc.isotropic[midx];
+                    const V3 attenuation = lambert_color(sc, m, rec.u, rec.v, rec.p);
+                    Onb uvw;
+                    if (lamb) uvw = onb_from_w(rec.normal);
+                    V3 dir;
+                    bool from_light = false;
+                    if (a.light_type != -1) from_light = random_float(rng) < 0.5; /* mixture_pdf::generate, pdf.cuh:96-103 */
+                    if (from_light) dir = light_random(sc, a.light_type, a.light_idx, rec.p, rng);
+                    else if (lamb) dir = onb_local(uvw, random_cosine_direction(rng));
+                    else dir = random_unit_vector(rng);
+                    /* srec.pdf_ptr->value(dir): cosine_pdf / sphere_pdf (pdf.cuh:29-32,45-49) */
+                    float mat_pdf;
+                    if (lamb) {
+                        const float cosine_theta = vdot(vunit(dir), uvw.w);
+                        mat_pdf = mort_fmaxf(0, (float)((double)cosine_theta / 3.1415926));
+                    } else {
+                        mat_pdf = (float)(1 / (4 * 3.1415926));
+                    }
+                    float pdf = mat_pdf;
+                    if (a.light_type != -1) /* mixture_pdf::value, pdf.cuh:91-93 */
+                        pdf = (float)(0.5 * (double)light_pdf_value(sc, a.light_type, a.light_idx, rec.p, dir) + 0.5 * (double)mat_pdf);
+                    float scattering_pdf; /* materials.cuh:51-55,195-198 */
+                    if (lamb) {
+                        const float cos_theta = vdot(rec.normal, vunit(dir));
+                        scattering_pdf = (cos_theta < 0) ? 0.0f : (float)((double)cos_theta / 3.141592565);
+                    } else {
+                        scattering_pdf = (float)(1 / (4 * 3.1415926));
+                    }
+                    ray.o = rec.p; ray.d = dir; ray.tm = ray_time0; /* ray(rec.p, dir, r.time()) */
+                    StackEntry e;
+                    e.kx = scattering_pdf * attenuation.x; e.ky = scattering_pdf * attenuation.y; e.kz = scattering_pdf * attenuation.z;
+                    e.rp = 1 / pdf;
+                    stack[iter] = e;
+                    iter++;
+                } else { /* diffuse_light (materials.cuh:151-163) or unknown tag: no scatter */
+                    V3 emission = mk(0, 0, 0);
+                    if (mtype == MORT_MAT_DIFFUSE_LIGHT && rec.front_face)
+                        emission = lambert_color(sc, sc.dlight[midx], rec.u, rec.v, rec.p);
+                    final_value = emission;
+                    done = true;
+                }
+            }
+        }
+        if (done) { /* unwind (camera.cuh:165-173) and accumulate (camera.cuh:190) */
+            while (iter > 0) {
+                iter--;
+                const StackEntry e = stack[iter];
+                const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
+                final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
+            }
+            pixel_color = vadd(pixel_color, final_value);
+            s++;
+            s_i++;
+            if (s_i == a.sqrt_spp) { s_i = 0; s_j++; }
+            fresh = true;
+        }
+    }
+
+    /* camera.cuh:194-207 */
+    pixel_color = vscale(a.pixel_samples_scale, pixel_color);
+    if (pixel_color.x != pixel_color.x) pixel_color.x = 0.0f;
+    if (pixel_color.y != pixel_color.y) pixel_color.y = 0.0f;
+    if (pixel_color.z != pixel_color.z) pixel_color.z = 0.0f;
+    if (a.accum) { a.accum[3 * lofs] = pixel_color.x; a.accum[3 * lofs + 1] = pixel_color.y; a.accum[3 * lofs + 2] = pixel_color.z; }
+    uchar4 out;
+    {
+        float c[3] = {mort_sqrtf(pixel_color.x), mort_sqrtf(pixel_color.y), mort_sqrtf(pixel_color.z)};
+        unsigned char b[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float v = c[k];
+            if (v < 0.0f) v = 0.0f;
+            if (v > 0.999f) v = 0.999f;
+            b[k] = (unsigned char)mort_f2i(256 * v);
+        }
+        out.x = b[0]; out.y = b[1]; out.z = b[2]; out.w = 255;
+    }
+    a.rgba[lofs] = out;
+    if (a.seg_px) a.seg_px[lofs] = segments;
+
+    {
+        mort_rng_state st;
+        st.d = rng.d; st.v[0] = rng.v0; st.v[1] = rng.v1; st.v[2] = rng.v2; st.v[3] = rng.v3; st.v[4] = rng.v4;
+        st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
+        a.states[lofs] = st;
+    }
+    atomicAdd(&a.counters[0], (unsigned long long)segments);
+    atomicAdd(&a.counters[1], (unsigned long long)rng.draws);
+}
+
+/* ---- seeding: curand_init(seed, subsequence, 0) ---- */
+struct SeedArgs {
+    mort_rng_state *states;
+    const uint32_t *mats; /* [levels][160][5]: A^(2^67 * 4^k), row i = image of state bit i */
+    int levels;
+    int width, local_rows, rank, nranks, rows_per_block;
+    uint32_t d0, v0, v1, v2, v3, v4; /* scrambled seed */
+};
+
+extern "C" __global__ void __launch_bounds__(256)
+seed_kernel(const SeedArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = a.width * a.local_rows;
+    if (i >= n) return;
+    const int ly = i / a.width, x = i - ly * a.width;
+    const int y = global_row(ly, a.rank, a.nranks, a.rows_per_block);
+    unsigned long long p = (unsigned long long)x + (unsigned long long)y * (unsigned long long)a.width;
+    uint32_t v[5] = {a.v0, a.v1, a.v2, a.v3, a.v4};
+    for (int k = 0; p != 0 && k < a.levels; k++, p >>= 2) {
+        const uint32_t *m = a.mats + (size_t)k * 160 * 5;
+        const int reps = (int)(p & 3ull);
+        for (int t = 0; t < reps; t++) {
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
+            for (int wv = 0; wv < 5; wv++) {
+                const uint32_t word = v[wv];
+                for (int b = 0; b < 32; b++) {
+                    const uint32_t mask = 0u - ((word >> b) & 1u);
+                    const uint32_t *row = m + (wv * 32 + b) * 5;
+                    r0 ^= row[0] & mask; r1 ^= row[1] & mask; r2 ^= row[2] & mask; r3 ^= row[3] & mask; r4 ^= row[4] & mask;
+                }
+            }
+            v[0] = r0; v[1] = r1; v[2] = r2; v[3] = r3; v[4] = r4;
+        }
+    }
+    mort_rng_state st;
+    st.d = a.d0; st.v[0] = v[0]; st.v[1] = v[1]; st.v[2] = v[2]; st.v[3] = v[3]; st.v[4] = v[4];
+    st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
+    a.states[i] = st;
+}
+
+/* ====================================================================== host */
+
+#define SEQ_LEVELS 32
+
+struct mort_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string last_error;
+    /* scene */
+    void *d_scene = nullptr;
+    DScene sc{};
+    bool have_world = false;
+    std::vector<int> list_types, list_idxs;        /* host copy, to validate the light object at render */
+    int list_first[MORT_NUM_HITTABLE_LIST]{}, list_count[MORT_NUM_HITTABLE_LIST]{};
+    int n_wspheres = 0, n_wquads = 0, n_lists = 0;
+    /* partition */
+    mort_partition part{0, 1, 8};
+    /* rng */
+    mort_rng_state *d_states = nullptr;
+    int rng_w = 0, rng_h = 0, rng_local_rows = 0;
+    uint32_t *d_seqmats = nullptr;
+    /* scratch */
+    void *d_rgba = nullptr, *d_accum = nullptr, *d_segpx = nullptr;
+    size_t rgba_cap = 0, accum_cap = 0, segpx_cap = 0;
+    unsigned long long *d_counters = nullptr;
+};
+
+static int hip_fail(mort_ctx *c, hipError_t e, const char *what) {
+    if (c) c->last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return MORT_ERR_HIP;
+}
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); } while (0)
+
+extern "C" const char *mort_hip_strerror(int st) {
+    switch (st) {
+    case MORT_OK: return "ok";
+    case MORT_ERR_INVALID: return "invalid argument";
+    case MORT_ERR_NO_DEVICE: return "no usable HIP device (gfx950 required)";
+    case MORT_ERR_HIP: return "HIP runtime error";
+    case MORT_ERR_NO_WORLD: return "no world uploaded";
+    case MORT_ERR_NO_RNG: return "RNG states not seeded/loaded for this image size";
+    case MORT_ERR_UNSUPPORTED: return "scene graph / mode not supported by the kernels";
+    case MORT_ERR_CAPACITY: return "capacity exceeded";
+    case MORT_ERR_NOMEM: return "out of memory";
+    }
+    return "unknown status";
+}
+extern "C" const char *mort_hip_last_error(const mort_ctx *c) { return c ? c->last_error.c_str() : ""; }
+
+static int local_rows_for(const mort_partition &p, int height) {
+    int n = 0;
+    const int rpb = p.rows_per_block;
+    const int nblocks = (height + rpb - 1) / rpb;
+    for (int b = p.rank; b < nblocks; b += p.nranks) {
+        int r0 = b * rpb, r1 = r0 + rpb;
+        if (r1 > height) r1 = height;
+        n += r1 - r0;
+    }
+    return n;
+}
+static int global_row_host(const mort_partition &p, int ly) {
+    const int lb = ly / p.rows_per_block, within = ly % p.rows_per_block;
+    return (lb * p.nranks + p.rank) * p.rows_per_block + within;
+}
+
+extern "C" int mort_hip_local_rows(const mort_ctx *c, int height) { return c ? local_rows_for(c->part, height) : 0; }
+extern "C" int mort_hip_global_row(const mort_ctx *c, int ly) { return c ? global_row_host(c->part, ly) : 0; }
+
+/* GF(2) 160x160 matrix helpers for the sequence skip (own implementation of the
+ * published XORWOW jump: state(n + 2^67 k) = M^k state(n), d unchanged). */
+struct XMat { uint32_t row[160][5]; };
+static void xmat_apply(const XMat &m, const uint32_t v[5], uint32_t out[5]) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 5; w++)
+        for (int b = 0; b < 32; b++)
+            if ((v[w] >> b) & 1u) for (int k = 0; k < 5; k++) r[k] ^= m.row[w * 32 + b][k];
+    std::memcpy(out, r, sizeof r);
+}
+static void xmat_square(const XMat &a, XMat &out) { for (int i = 0; i < 160; i++) xmat_apply(a, a.row[i], out.row[i]); }
+static void build_seq_matrices(std::vector<XMat> &seq) {
+    XMat *a = new XMat, *b = new XMat;
+    for (int i = 0; i < 160; i++) {
+        uint32_t v[5] = {0, 0, 0, 0, 0};
+        v[i / 32] = 1u << (i % 32);
+        uint32_t t = v[0] ^ (v[0] >> 2);
+        uint32_t n4 = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
+        a->row[i][0] = v[1]; a->row[i][1] = v[2]; a->row[i][2] = v[3]; a->row[i][3] = v[4]; a->row[i][4] = n4;
+    }
+    for (int k = 0; k < 67; k++) { xmat_square(*a, *b); std::swap(a, b); }
+    seq.resize(SEQ_LEVELS);
+    seq[0] = *a;
+    for (int k = 1; k < SEQ_LEVELS; k++) { xmat_square(seq[k - 1], *b); xmat_square(*b, seq[k]); }
+    delete a; delete b;
+}
+
+extern "C" int mort_hip_init(int device, mort_ctx **out) {
+    if (!out) return MORT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return MORT_ERR_NO_DEVICE;
+    mort_ctx *c = new (std::nothrow) mort_ctx;
+    if (!c) return MORT_ERR_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return MORT_ERR_NO_DEVICE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return MORT_ERR_NO_DEVICE; }
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MORT_ERR_NO_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipMalloc(&c->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess) {
+        mort_hip_shutdown(c);
+        return MORT_ERR_HIP;
+    }
+    *out = c;
+    return MORT_OK;
+}
+
+extern "C" void mort_hip_shutdown(mort_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    hipFree(c->d_scene); hipFree(c->d_states); hipFree(c->d_seqmats);
+    hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mort_hip_set_partition(mort_ctx *c, const mort_partition *p) {
+    if (!c || !p) return MORT_ERR_INVALID;
+    if (p->nranks < 1 || p->rank < 0 || p->rank >= p->nranks || p->rows_per_block < 8 || (p->rows_per_block % 8) != 0)
+        return MORT_ERR_INVALID;
+    c->part = *p;
+    /* RNG states are laid out per partition: force a re-seed */
+    c->rng_w = c->rng_h = c->rng_local_rows = 0;
+    return MORT_OK;
+}
+
+/* ---- validation of every index the kernels will dereference ---- */
+static bool tex_ok(const mort_world *w, int type, int idx, int depth) {
+    switch (type) {
+    case MORT_TEXTURE_SOLID: return idx >= 0 && idx < w->texs.num_solid_colors;
+    case MORT_TEXTURE_CHECKER: {
+        if (idx < 0 || idx >= w->texs.num_checker_textures || depth > 6) return false;
+        const mort_checker_texture &c = w->texs.host_checker_texture[idx];
+        return tex_ok(w, c.evenTextureType, c.evenTextureIdx, depth + 1) && tex_ok(w, c.oddTextureType, c.oddTextureIdx, depth + 1);
+    }
+    case MORT_TEXTURE_IMAGE: return idx >= 0 && idx < w->texs.num_image_textures;
+    case MORT_TEXTURE_NOISE: return idx >= 0 && idx < w->texs.num_noise_textures;
+    }
+    return true; /* unknown tag: the error pattern, no table access */
+}
+static bool mat_ok(const mort_world *w, int type, int idx) {
+    const mort_world_materials &m = w->mats;
+    switch (type) {
+    case MORT_MAT_LAMBERTIAN: return idx >= 0 && idx < m.num_lambertians && tex_ok(w, m.host_lambertian[idx].texType, m.host_lambertian[idx].texIdx, 0);
+    case MORT_MAT_METAL: return idx >= 0 && idx < m.num_metals;
+    case MORT_MAT_DIELECTRIC: return idx >= 0 && idx < m.num_dielectrics;
+    case MORT_MAT_DIFFUSE_LIGHT: return idx >= 0 && idx < m.num_diffuse_lights && tex_ok(w, m.host_diffuse_light[idx].texType, m.host_diffuse_light[idx].texIdx, 0);
+    case MORT_MAT_ISOTROPIC: return idx >= 0 && idx < m.num_isotropics && tex_ok(w, m.host_isotropic[idx].texType, m.host_isotropic[idx].texIdx, 0);
+    }
+    return true; /* unknown tag: treated as "does not scatter", no table access */
+}
+static int validate_world(const mort_world *w) {
+    const mort_world_objects &o = w->objs;
+    if (o.num_spheres < 0 || o.num_spheres > MORT_NUM_SPHERES || o.num_quads < 0 || o.num_quads > MORT_NUM_QUADS ||
+        o.num_translates < 0 || o.num_translates > MORT_NUM_TRANSLATE || o.num_rotate_y < 0 || o.num_rotate_y > MORT_NUM_ROTATE_Y ||
+        o.num_constant_medium < 0 || o.num_constant_medium > MORT_NUM_CONSTANT_MEDIUM ||
+        o.num_hittable_list < 0 || o.num_hittable_list > MORT_NUM_HITTABLE_LIST || o.num_bvh < 0 || o.num_bvh > MORT_NUM_BVH)
+        return MORT_ERR_CAPACITY;
+    for (int i = 0; i < o.num_spheres; i++) if (!mat_ok(w, o.host_sphere[i].mat_type, o.host_sphere[i].mat_idx)) return MORT_ERR_INVALID;
+    for (int i = 0; i < o.num_quads; i++) if (!mat_ok(w, o.host_quad[i].mat_type, o.host_quad[i].mat_idx)) return MORT_ERR_INVALID;
+    for (int i = 0; i < o.num_constant_medium; i++) if (!mat_ok(w, o.host_constant_medium[i].mat_type, o.host_constant_medium[i].mat_idx)) return MORT_ERR_INVALID;
+    for (int i = 0; i < o.num_hittable_list; i++) if (o.host_hittable_list[i].num_objs < 0 || o.host_hittable_list[i].num_objs > MORT_LIST_MAX_OBJS) return MORT_ERR_INVALID;
+    return MORT_OK;
+}
+
+template <typename T>
+static size_t place(std::vector<unsigned char> &blob, const std::vector<T> &v) {
+    size_t off = (blob.size() + 15) & ~(size_t)15;
+    blob.resize(off + v.size() * sizeof(T) + 16, 0); /* 16 B tail so empty arrays still get distinct, valid addresses */
+    if (!v.empty()) std::memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
+    return off;
+}
+
+extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
+    if (!c || !w) return MORT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int st = validate_world(w);
+    if (st != MORT_OK) return st;
+    mortc::Compiler comp;
+    comp.w = w;
+    comp.run();
+    if (comp.out.status != MORT_OK) return comp.out.status;
+    mortc::Compiled &o = comp.out;
+
+    std::vector<unsigned char> blob;
+    const size_t o_items = place(blob, o.items), o_sub = place(blob, o.subitems), o_nodes = place(blob, o.nodes);
+    const size_t o_sph = place(blob, o.spheres), o_quads = place(blob, o.quads), o_xf = place(blob, o.xforms);
+    const size_t o_media = place(blob, o.media);
+    const size_t o_lamb = place(blob, o.lambert), o_metal = place(blob, o.metal), o_diel = place(blob, o.dielectric);
+    const size_t o_dl = place(blob, o.dlight), o_iso = place(blob, o.isotropic);
+    const size_t o_solid = place(blob, o.solid), o_chk = place(blob, o.checker), o_img = place(blob, o.image);
+    const size_t hot_bytes = (blob.size() + 15) & ~(size_t)15;
+    const size_t o_wsph = place(blob, o.wspheres), o_wquads = place(blob, o.wquads);
+    const size_t o_lt = place(blob, o.list_types), o_li = place(blob, o.list_idxs);
+    const size_t o_noise = place(blob, o.noise), o_tex = place(blob, o.texels);
+
+    void *d = nullptr;
+    HIPCHK(c, hipMalloc(&d, blob.size()));
+    hipError_t e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(d); return hip_fail(c, e, "hipMemcpy(scene)"); }
+    if (c->d_scene) hipFree(c->d_scene);
+    c->d_scene = d;
+    const unsigned char *base = (const unsigned char *)d;
+    DScene &s = c->sc;
+    std::memset(&s, 0, sizeof s);
+    s.items = (const DItem *)(base + o_items); s.n_items = (int)o.items.size();
+    s.subitems = (const DItem *)(base + o_sub); s.n_subitems = (int)o.subitems.size();
+    s.nodes = (const DBvhNode *)(base + o_nodes); s.n_nodes = (int)o.nodes.size();
+    s.spheres = (const DSphere *)(base + o_sph); s.n_spheres = (int)o.spheres.size();
+    s.quads = (const DQuad *)(base + o_quads); s.n_quads = (int)o.quads.size();
+    s.xforms = (const DXform *)(base + o_xf); s.n_xforms = (int)o.xforms.size();
+    s.neg_inv_density = (const double *)(base + o_media); s.n_media = (int)o.media.size();
+    s.lambert = (const DLambert *)(base + o_lamb); s.metal = (const DMetal *)(base + o_metal);
+    s.dielectric = (const DDielectric *)(base + o_diel);
+    s.dlight = (const DLambert *)(base + o_dl); s.isotropic = (const DLambert *)(base + o_iso);
+    s.solid = (const DSolid *)(base + o_solid); s.checker = (const DChecker *)(base + o_chk); s.image = (const DImage *)(base + o_img);
+    s.texels = base + o_tex; s.noise = (const float *)(base + o_noise);
+    s.wspheres = (const DSphere *)(base + o_wsph); s.wquads = (const DQuad *)(base + o_wquads);
+    s.list_types = (const int *)(base + o_lt); s.list_idxs = (const int *)(base + o_li);
+    for (int i = 0; i < MORT_NUM_HITTABLE_LIST; i++) { s.list_first[i] = o.list_first[i]; s.list_count[i] = o.list_count[i]; }
+    s.blob_bytes = (uint32_t)hot_bytes;
+    s.lds_bytes = (uint32_t)hot_bytes;
+    c->list_types = o.list_types; c->list_idxs = o.list_idxs;
+    for (int i = 0; i < MORT_NUM_HITTABLE_LIST; i++) { c->list_first[i] = o.list_first[i]; c->list_count[i] = o.list_count[i]; }
+    c->n_wspheres = (int)o.wspheres.size(); c->n_wquads = (int)o.wquads.size(); c->n_lists = w->objs.num_hittable_list;
+    c->have_world = true;
+    return MORT_OK;
+}
+
+static int ensure_states(mort_ctx *c, int width, int height) {
+    const int lr = local_rows_for(c->part, height);
+    if (c->d_states && c->rng_w == width && c->rng_h == height && c->rng_local_rows == lr) return MORT_OK;
+    if (c->d_states) { hipFree(c->d_states); c->d_states = nullptr; }
+    c->rng_w = c->rng_h = c->rng_local_rows = 0;
+    size_t n = (size_t)width * (size_t)(lr > 0 ? lr : 1);
+    HIPCHK(c, hipMalloc((void **)&c->d_states, n * sizeof(mort_rng_state)));
+    c->rng_w = width; c->rng_h = height; c->rng_local_rows = lr;
+    return MORT_OK;
+}
+
+extern "C" int mort_hip_rng_seed(mort_ctx *c, uint64_t seed, int width, int height) {
+    if (!c || width <= 0 || height <= 0) return MORT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_seqmats) {
+        std::vector<XMat> seq;
+        build_seq_matrices(seq);
+        HIPCHK(c, hipMalloc((void **)&c->d_seqmats, seq.size() * sizeof(XMat)));
+        HIPCHK(c, hipMemcpy(c->d_seqmats, seq.data(), seq.size() * sizeof(XMat), hipMemcpyHostToDevice));
+    }
+    int st = ensure_states(c, width, height);
+    if (st != MORT_OK) return st;
+    SeedArgs a;
+    a.states = c->d_states; a.mats = c->d_seqmats; a.levels = SEQ_LEVELS;
+    a.width = width; a.local_rows = c->rng_local_rows;
+    a.rank = c->part.rank; a.nranks = c->part.nranks; a.rows_per_block = c->part.rows_per_block;
+    /* curand_init seed scramble (cuRAND XORWOW, curand_kernel.h) */
+    const uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u;
+    const uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    const uint32_t t0 = 1099087573u * s0;
+    const uint32_t t1 = 2591861531u * s1;
+    a.d0 = 6615241u + t1 + t0;
+    a.v0 = 123456789u + t0; a.v1 = 362436069u ^ t0; a.v2 = 521288629u + t1; a.v3 = 88675123u ^ t1; a.v4 = 5783321u + t0;
+    const int n = width * c->rng_local_rows;
+    if (n > 0) {
+        hipLaunchKernelGGL(seed_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return MORT_OK;
+}
+
+extern "C" int mort_hip_rng_load(mort_ctx *c, const mort_rng_state *states, int width, int height) {
+    if (!c || !states || width <= 0 || height <= 0) return MORT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    int st = ensure_states(c, width, height);
+    if (st != MORT_OK) return st;
+    for (int ly = 0; ly < c->rng_local_rows; ly++) {
+        const int y = global_row_host(c->part, ly);
+        HIPCHK(c, hipMemcpy(c->d_states + (size_t)ly * width, states + (size_t)y * width, (size_t)width * sizeof(mort_rng_state), hipMemcpyHostToDevice));
+    }
+    return MORT_OK;
+}
+
+extern "C" int mort_hip_rng_store(mort_ctx *c, mort_rng_state *states, int width, int height) {
+    if (!c || !states || width <= 0 || height <= 0) return MORT_ERR_INVALID;
+    if (!c->d_states || c->rng_w != width || c->rng_h != height) return MORT_ERR_NO_RNG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int ly = 0; ly < c->rng_local_rows; ly++) {
+        const int y = global_row_host(c->part, ly);
+        HIPCHK(c, hipMemcpy(states + (size_t)y * width, c->d_states + (size_t)ly * width, (size_t)width * sizeof(mort_rng_state), hipMemcpyDeviceToHost));
+    }
+    return MORT_OK;
+}
+
+static V3 to_v3(const mort_vec3 &v) { V3 r; r.x = v.e[0]; r.y = v.e[1]; r.z = v.e[2]; return r; }
+
+static int check_light(const mort_ctx *c, int type, int idx) {
+    if (type == -1) return MORT_OK;
+    if (type == MORT_OBJ_SPHERE) return (idx >= 0 && idx < c->n_wspheres) ? MORT_OK : MORT_ERR_INVALID;
+    if (type == MORT_OBJ_QUAD) return (idx >= 0 && idx < c->n_wquads) ? MORT_OK : MORT_ERR_INVALID;
+    if (type == MORT_OBJ_HITTABLE_LIST) {
+        if (idx < 0 || idx >= c->n_lists || idx >= MORT_NUM_HITTABLE_LIST) return MORT_ERR_INVALID;
+        if (c->list_count[idx] <= 0) return MORT_ERR_INVALID;
+        for (int i = 0; i < c->list_count[idx]; i++) {
+            const int t = c->list_types[c->list_first[idx] + i], k = c->list_idxs[c->list_first[idx] + i];
+            if (t == MORT_OBJ_SPHERE) { if (k < 0 || k >= c->n_wspheres) return MORT_ERR_INVALID; }
+            else if (t == MORT_OBJ_QUAD) { if (k < 0 || k >= c->n_wquads) return MORT_ERR_INVALID; }
+            else if (t == MORT_OBJ_HITTABLE_LIST) return MORT_ERR_UNSUPPORTED; /* nested light lists */
+        }
+        return MORT_OK;
+    }
+    return MORT_OK; /* any other tag samples nothing: pdf 0, direction (1,0,0) (objects.cuh:961,978) */
+}
+
+extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum,
+                                      void *stream, mort_stats *stats) {
+    if (!c || !cam || !d_rgba) return MORT_ERR_INVALID;
+    if (mode == MORT_MODE_WAVE) return MORT_ERR_UNSUPPORTED;
+    if (mode != MORT_MODE_MEGA) return MORT_ERR_INVALID;
+    if (!c->have_world) return MORT_ERR_NO_WORLD;
+    const int W = cam->image_width, H = cam->image_height;
+    if (W <= 0 || H <= 0 || cam->sqrt_spp < 0) return MORT_ERR_INVALID;
+    if (cam->bounce_limit < 0 || cam->bounce_limit > MORT_MAX_BOUNCE_LIMIT) return MORT_ERR_CAPACITY;
+    if (!c->d_states || c->rng_w != W || c->rng_h != H) return MORT_ERR_NO_RNG;
+    int st = check_light(c, cam->light_obj_type, cam->light_obj_idx);
+    if (st != MORT_OK) return st;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+
+    RenderArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.sc = c->sc;
+    a.width = W; a.height = H;
+    a.sqrt_spp = cam->sqrt_spp; a.bounce_limit = cam->bounce_limit;
+    a.recip_sqrt_spp = cam->recip_sqrt_spp; a.pixel_samples_scale = cam->pixel_samples_scale;
+    a.background = to_v3(cam->background); a.center = to_v3(cam->center); a.pixel00 = to_v3(cam->pixel00_loc);
+    a.du = to_v3(cam->pixel_delta_u); a.dv = to_v3(cam->pixel_delta_v);
+    a.defocus_u = to_v3(cam->defocus_disk_u); a.defocus_v = to_v3(cam->defocus_disk_v);
+    a.defocus_angle = cam->defocus_angle;
+    a.light_type = cam->light_obj_type; a.light_idx = cam->light_obj_idx;
+    a.rank = c->part.rank; a.nranks = c->part.nranks; a.rows_per_block = c->part.rows_per_block;
+    a.local_rows = c->rng_local_rows;
+    a.states = c->d_states;
+    a.rgba = (uchar4 *)d_rgba; a.accum = (float *)d_accum; a.seg_px = (uint32_t *)c->d_segpx;
+    a.counters = c->d_counters;
+
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), s));
+    const int tiles = ((W + 7) / 8) * ((a.local_rows + 7) / 8);
+    const int waves_per_block = 4;
+    const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
+    if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
+    if (blocks > 0) {
+        hipLaunchKernelGGL(mega_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, s, a);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (stats) {
+        HIPCHK(c, hipEventRecord(c->ev1, s));
+        HIPCHK(c, hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        unsigned long long cnt[2] = {0, 0};
+        HIPCHK(c, hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+        std::memset(stats, 0, sizeof *stats);
+        stats->seconds = ms * 1e-3;
+        stats->segments = cnt[0];
+        stats->rng_draws = cnt[1];
+        stats->pixels = (uint64_t)W * (uint64_t)a.local_rows;
+        stats->eff_samples = stats->pixels * (uint64_t)(cam->sqrt_spp * cam->sqrt_spp);
+        stats->algorithmic_hbm_bytes = stats->pixels * (uint64_t)(100 + (d_accum ? 12 : 0));
+        stats->scene_in_lds = 0;
+        stats->local_rows = a.local_rows;
+        hipFuncAttributes fa;
+        if (hipFuncGetAttributes(&fa, (const void *)mega_kernel) == hipSuccess) {
+            stats->kernel_vgprs = fa.numRegs;
+            stats->kernel_lds_bytes = (int)fa.sharedSizeBytes;
+        }
+    }
+    return MORT_OK;
+}
+
+static int ensure_buf(mort_ctx *c, void **p, size_t *cap, size_t need) {
+    if (*cap >= need && *p) return MORT_OK;
+    if (*p) { hipFree(*p); *p = nullptr; *cap = 0; }
+    HIPCHK(c, hipMalloc(p, need ? need : 16));
+    *cap = need;
+    return MORT_OK;
+}
+
+extern "C" int mort_hip_render(mort_ctx *c, const mort_camera *cam, int mode, uint8_t *rgba_out, float *accum_out,
+                               uint32_t *segments_px_out, mort_stats *stats) {
+    if (!c || !cam || !rgba_out) return MORT_ERR_INVALID;
+    const int W = cam->image_width, H = cam->image_height;
+    if (W <= 0 || H <= 0) return MORT_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int lr = local_rows_for(c->part, H);
+    const size_t npx = (size_t)W * (size_t)lr;
+    int st;
+    if ((st = ensure_buf(c, &c->d_rgba, &c->rgba_cap, npx * 4)) != MORT_OK) return st;
+    if (accum_out && (st = ensure_buf(c, &c->d_accum, &c->accum_cap, npx * 12)) != MORT_OK) return st;
+    if (segments_px_out) { if ((st = ensure_buf(c, &c->d_segpx, &c->segpx_cap, npx * 4)) != MORT_OK) return st; }
+    else if (c->d_segpx) { hipFree(c->d_segpx); c->d_segpx = nullptr; c->segpx_cap = 0; }
+    mort_stats local;
+    st = mort_hip_render_device(c, cam, mode, c->d_rgba, accum_out ? c->d_accum : nullptr, nullptr, &local);
+    if (st != MORT_OK) return st;
+    if (stats) *stats = local;
+    for (int ly = 0; ly < lr; ly++) {
+        const int y = global_row_host(c->part, ly);
+        HIPCHK(c, hipMemcpy(rgba_out + (size_t)y * W * 4, (uint8_t *)c->d_rgba + (size_t)ly * W * 4, (size_t)W * 4, hipMemcpyDeviceToHost));
+        if (accum_out) HIPCHK(c, hipMemcpy(accum_out + (size_t)y * W * 3, (float *)c->d_accum + (size_t)ly * W * 3, (size_t)W * 12, hipMemcpyDeviceToHost));
+        if (segments_px_out) HIPCHK(c, hipMemcpy(segments_px_out + (size_t)y * W, (uint32_t *)c->d_segpx + (size_t)ly * W, (size_t)W * 4, hipMemcpyDeviceToHost));
+    }
+    return MORT_OK;
+}

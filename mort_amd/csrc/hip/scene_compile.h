@@ -1,0 +1,282 @@
+/*
+ * scene_compile.h -- host side of mort_hip_upload_world(): turns a mort_world
+ * (the reference's tagged object graph) into the flat DScene arrays of
+ * dev_scene.h.  Replaces world::toDevice() (world.cuh:98-102), which copies
+ * the object arrays verbatim into __device__/__constant__ symbols.
+ */
+#ifndef MORT_SCENE_COMPILE_H
+#define MORT_SCENE_COMPILE_H
+
+#include <cstring>
+#include <vector>
+
+#include "dev_scene.h"
+#include "mort_hip.h"
+
+namespace mortc {
+
+static const int kMaxChain = 8;
+static const int kMaxDepth = 16;
+
+struct Ref { int kind; int idx; int cf, cc; }; /* kind: 1 sphere, 2 quad, 3 medium (world indices) */
+
+struct Compiled {
+    std::vector<DItem> items, subitems;
+    std::vector<DBvhNode> nodes;
+    std::vector<DSphere> spheres, wspheres;
+    std::vector<DQuad> quads, wquads;
+    std::vector<DXform> xforms;
+    std::vector<double> media;
+    std::vector<DLambert> lambert, dlight, isotropic;
+    std::vector<DMetal> metal;
+    std::vector<DDielectric> dielectric;
+    std::vector<DSolid> solid;
+    std::vector<DChecker> checker;
+    std::vector<DImage> image;
+    std::vector<unsigned char> texels;
+    std::vector<unsigned char> noise;
+    std::vector<int> list_types, list_idxs;
+    int list_first[MORT_NUM_HITTABLE_LIST], list_count[MORT_NUM_HITTABLE_LIST];
+    int status = MORT_OK;
+};
+
+static inline DSphere to_dsphere(const mort_sphere &s) {
+    DSphere d;
+    d.cx = s.center1.e[0]; d.cy = s.center1.e[1]; d.cz = s.center1.e[2]; d.radius = s.radius;
+    d.vx = s.moves ? s.center_vec.e[0] : 0.0f;
+    d.vy = s.moves ? s.center_vec.e[1] : 0.0f;
+    d.vz = s.moves ? s.center_vec.e[2] : 0.0f;
+    d.mat = DREF(s.mat_type, s.mat_idx) | (s.moves ? 0x80000000u : 0u);
+    return d;
+}
+static inline DQuad to_dquad(const mort_quad &q) {
+    DQuad d;
+    std::memset(&d, 0, sizeof d);
+    for (int k = 0; k < 3; k++) {
+        d.Q[k] = q.Q.e[k]; d.u[k] = q.u.e[k]; d.v[k] = q.v.e[k]; d.n[k] = q.normal.e[k]; d.w[k] = q.w.e[k];
+    }
+    d.D = q.D; d.area = q.area; d.mat = DREF(q.mat_type, q.mat_idx);
+    return d;
+}
+
+struct Compiler {
+    const mort_world *w;
+    Compiled out;
+
+    void fail(int st) { if (out.status == MORT_OK) out.status = st; }
+
+    int push_chain(int pf, int pc, const DXform &x) {
+        if (pc + 1 > kMaxChain) { fail(MORT_ERR_CAPACITY); return 0; }
+        int first = (int)out.xforms.size();
+        for (int k = 0; k < pc; k++) { DXform c = out.xforms[pf + k]; out.xforms.push_back(c); }
+        out.xforms.push_back(x);
+        return first;
+    }
+
+    /* hitDispatch (objects.cuh:858-887) unrolled into an ordered list of leaves */
+    void flatten(int type, int idx, int cf, int cc, int depth, std::vector<Ref> &refs) {
+        if (depth > kMaxDepth) { fail(MORT_ERR_CAPACITY); return; }
+        const mort_world_objects &o = w->objs;
+        switch (type) {
+        case MORT_OBJ_SPHERE:
+            if (idx < 0 || idx >= o.num_spheres) { fail(MORT_ERR_INVALID); return; }
+            refs.push_back({1, idx, cf, cc});
+            break;
+        case MORT_OBJ_QUAD:
+            if (idx < 0 || idx >= o.num_quads) { fail(MORT_ERR_INVALID); return; }
+            refs.push_back({2, idx, cf, cc});
+            break;
+        case MORT_OBJ_TRANSLATE: {
+            if (idx < 0 || idx >= o.num_translates) { fail(MORT_ERR_INVALID); return; }
+            const mort_translate &t = o.host_translate[idx];
+            DXform x; x.kind = XF_TRANSLATE; x.a = t.offset.e[0]; x.b = t.offset.e[1]; x.c = t.offset.e[2];
+            int nf = push_chain(cf, cc, x);
+            flatten(t.obj_type, t.obj_idx, nf, cc + 1, depth + 1, refs);
+            break;
+        }
+        case MORT_OBJ_ROTATE_Y: {
+            if (idx < 0 || idx >= o.num_rotate_y) { fail(MORT_ERR_INVALID); return; }
+            const mort_rotate_y &r = o.host_rotate_y[idx];
+            DXform x; x.kind = XF_ROTATE_Y; x.a = r.sin_theta; x.b = r.cos_theta; x.c = 0;
+            int nf = push_chain(cf, cc, x);
+            flatten(r.obj_type, r.obj_idx, nf, cc + 1, depth + 1, refs);
+            break;
+        }
+        case MORT_OBJ_CONSTANT_MEDIUM:
+            if (idx < 0 || idx >= o.num_constant_medium) { fail(MORT_ERR_INVALID); return; }
+            refs.push_back({3, idx, cf, cc});
+            break;
+        case MORT_OBJ_HITTABLE_LIST: {
+            if (idx < 0 || idx >= o.num_hittable_list) { fail(MORT_ERR_INVALID); return; }
+            const mort_hittable_list &l = o.host_hittable_list[idx];
+            for (int i = 0; i < l.num_objs; i++) flatten(l.obj_types[i], l.obj_idxs[i], cf, cc, depth + 1, refs);
+            break;
+        }
+        default: /* OBJ_BVH and unknown tags: hitDispatch returns false */
+            break;
+        }
+    }
+
+    void emit_items(const std::vector<Ref> &refs, std::vector<DItem> &items, bool allow_medium) {
+        size_t i = 0;
+        while (i < refs.size()) {
+            const Ref &r = refs[i];
+            DItem it;
+            std::memset(&it, 0, sizeof it);
+            it.chain_first = r.cf; it.chain_count = r.cc;
+            if (r.kind == 3) {
+                if (!allow_medium) { fail(MORT_ERR_UNSUPPORTED); return; } /* a medium bounded by a medium */
+                const mort_constant_medium &m = w->objs.host_constant_medium[r.idx];
+                std::vector<Ref> b;
+                flatten(m.obj_type, m.obj_idx, r.cf, r.cc, 1, b);
+                it.kind = ITEM_MEDIUM;
+                it.first = (int)out.subitems.size();
+                emit_items(b, out.subitems, false);
+                it.count = (int)out.subitems.size() - it.first;
+                it.mat = DREF(m.mat_type, m.mat_idx);
+                it.medium = (int)out.media.size();
+                out.media.push_back(m.neg_inv_density);
+                items.push_back(it);
+                i++;
+                continue;
+            }
+            size_t j = i;
+            while (j < refs.size() && refs[j].kind == r.kind && refs[j].cf == r.cf && refs[j].cc == r.cc) j++;
+            if (r.kind == 1) {
+                it.kind = ITEM_SPHERES; it.first = (int)out.spheres.size();
+                for (size_t k = i; k < j; k++) out.spheres.push_back(to_dsphere(w->objs.host_sphere[refs[k].idx]));
+            } else {
+                it.kind = ITEM_QUADS; it.first = (int)out.quads.size();
+                for (size_t k = i; k < j; k++) out.quads.push_back(to_dquad(w->objs.host_quad[refs[k].idx]));
+            }
+            it.count = (int)(j - i);
+            items.push_back(it);
+            i = j;
+        }
+    }
+
+    /* one BVH leaf child -> prim code (kind << 15 | index in the compact arrays) */
+    uint32_t leaf_prim(int type, int idx) {
+        if (type == MORT_OBJ_SPHERE && idx >= 0 && idx < w->objs.num_spheres) {
+            out.spheres.push_back(to_dsphere(w->objs.host_sphere[idx]));
+            size_t at = out.spheres.size() - 1;
+            if (at >= 0x8000) { fail(MORT_ERR_CAPACITY); return 0; }
+            return (uint32_t)at;
+        }
+        if (type == MORT_OBJ_QUAD && idx >= 0 && idx < w->objs.num_quads) {
+            out.quads.push_back(to_dquad(w->objs.host_quad[idx]));
+            size_t at = out.quads.size() - 1;
+            if (at >= 0x8000) { fail(MORT_ERR_CAPACITY); return 0; }
+            return 0x8000u | (uint32_t)at;
+        }
+        fail(MORT_ERR_UNSUPPORTED); /* instances / media / lists as BVH leaves */
+        return 0;
+    }
+
+    /* pre-order emission of reference node `n` (objects.cuh:725-735) */
+    void emit_bvh_node(const mort_bvh &b, int n, int depth) {
+        if (depth > 64 || n < 0 || n >= MORT_MAX_BVH_NODES) { fail(MORT_ERR_INVALID); return; }
+        size_t id = out.nodes.size();
+        DBvhNode nd;
+        std::memset(&nd, 0, sizeof nd);
+        const mort_aabb &bb = b.bounding_boxes[n];
+        nd.xmin = bb.x.imin; nd.xmax = bb.x.imax; nd.ymin = bb.y.imin; nd.ymax = bb.y.imax; nd.zmin = bb.z.imin; nd.zmax = bb.z.imax;
+        out.nodes.push_back(nd);
+        bool leaf = !b.is_internal_node[n];
+        uint32_t prims = 0;
+        if (leaf) {
+            uint32_t pa = leaf_prim(b.left_children_types[n], b.left_children_idxs[n]);
+            uint32_t pb = pa;
+            if (!(b.left_children_types[n] == b.right_children_types[n] && b.left_children_idxs[n] == b.right_children_idxs[n]))
+                pb = leaf_prim(b.right_children_types[n], b.right_children_idxs[n]);
+            prims = pa | (pb << 16);
+        } else {
+            emit_bvh_node(b, b.left_children_idxs[n], depth + 1);
+            emit_bvh_node(b, b.right_children_idxs[n], depth + 1);
+        }
+        out.nodes[id].skip = (uint32_t)out.nodes.size() | (leaf ? 0x80000000u : 0u);
+        out.nodes[id].prims = prims;
+    }
+
+    static uint32_t tex_ref(int type, int idx) { return DREF(type & 0x7fff, idx & 0xffff); }
+
+    DLambert tex_material(int tex_type, int tex_idx) {
+        DLambert d;
+        d.r = d.g = d.b = 0; d.tex = tex_ref(tex_type, tex_idx);
+        if (tex_type == MORT_TEXTURE_SOLID && tex_idx >= 0 && tex_idx < w->texs.num_solid_colors) {
+            const mort_vec3 &c = w->texs.host_solid_color[tex_idx].color_value;
+            d.r = c.e[0]; d.g = c.e[1]; d.b = c.e[2]; d.tex = 0; /* colour inlined */
+        }
+        return d;
+    }
+
+    void run() {
+        const mort_world_objects &o = w->objs;
+        /* world::hit order (world.cuh:110-168) */
+        for (int i = 0; i < o.num_bvh; i++) {
+            if (o.host_bvh[i].skip) continue;
+            DItem it;
+            std::memset(&it, 0, sizeof it);
+            it.kind = ITEM_BVH; it.first = (int)out.nodes.size();
+            emit_bvh_node(o.host_bvh[i], 0, 0);
+            it.count = (int)out.nodes.size() - it.first;
+            out.items.push_back(it);
+        }
+        if (!w->bvh_mode) {
+            std::vector<Ref> refs;
+            for (int i = 0; i < o.num_spheres; i++) if (!o.host_sphere[i].skip) refs.push_back({1, i, 0, 0});
+            for (int i = 0; i < o.num_quads; i++) if (!o.host_quad[i].skip) refs.push_back({2, i, 0, 0});
+            for (int i = 0; i < o.num_translates; i++) if (!o.host_translate[i].skip) flatten(MORT_OBJ_TRANSLATE, i, 0, 0, 0, refs);
+            for (int i = 0; i < o.num_rotate_y; i++) if (!o.host_rotate_y[i].skip) flatten(MORT_OBJ_ROTATE_Y, i, 0, 0, 0, refs);
+            for (int i = 0; i < o.num_constant_medium; i++) if (!o.host_constant_medium[i].skip) refs.push_back({3, i, 0, 0});
+            for (int i = 0; i < o.num_hittable_list; i++) if (!o.host_hittable_list[i].skip) flatten(MORT_OBJ_HITTABLE_LIST, i, 0, 0, 0, refs);
+            emit_items(refs, out.items, true);
+        }
+        /* world-order copies for light sampling */
+        for (int i = 0; i < o.num_spheres; i++) out.wspheres.push_back(to_dsphere(o.host_sphere[i]));
+        for (int i = 0; i < o.num_quads; i++) out.wquads.push_back(to_dquad(o.host_quad[i]));
+        for (int i = 0; i < MORT_NUM_HITTABLE_LIST; i++) { out.list_first[i] = 0; out.list_count[i] = 0; }
+        for (int i = 0; i < o.num_hittable_list && i < MORT_NUM_HITTABLE_LIST; i++) {
+            const mort_hittable_list &l = o.host_hittable_list[i];
+            out.list_first[i] = (int)out.list_types.size();
+            out.list_count[i] = l.num_objs;
+            for (int k = 0; k < l.num_objs; k++) { out.list_types.push_back(l.obj_types[k]); out.list_idxs.push_back(l.obj_idxs[k]); }
+        }
+        /* materials */
+        const mort_world_materials &m = w->mats;
+        for (int i = 0; i < m.num_lambertians; i++) out.lambert.push_back(tex_material(m.host_lambertian[i].texType, m.host_lambertian[i].texIdx));
+        for (int i = 0; i < m.num_diffuse_lights; i++) out.dlight.push_back(tex_material(m.host_diffuse_light[i].texType, m.host_diffuse_light[i].texIdx));
+        for (int i = 0; i < m.num_isotropics; i++) out.isotropic.push_back(tex_material(m.host_isotropic[i].texType, m.host_isotropic[i].texIdx));
+        for (int i = 0; i < m.num_metals; i++) {
+            DMetal d; d.r = m.host_metal[i].albedo.e[0]; d.g = m.host_metal[i].albedo.e[1]; d.b = m.host_metal[i].albedo.e[2]; d.fuzz = m.host_metal[i].fuzz;
+            out.metal.push_back(d);
+        }
+        for (int i = 0; i < m.num_dielectrics; i++) { DDielectric d; d.ior = m.host_dielectric[i].ior; d.inv_ior = m.host_dielectric[i].inv_ior; out.dielectric.push_back(d); }
+        /* textures */
+        const mort_world_textures &t = w->texs;
+        for (int i = 0; i < t.num_solid_colors; i++) {
+            DSolid d; d.r = t.host_solid_color[i].color_value.e[0]; d.g = t.host_solid_color[i].color_value.e[1]; d.b = t.host_solid_color[i].color_value.e[2]; d.pad = 0;
+            out.solid.push_back(d);
+        }
+        for (int i = 0; i < t.num_checker_textures; i++) {
+            const mort_checker_texture &c = t.host_checker_texture[i];
+            DChecker d; d.inv_scale = c.inv_scale; d.even = tex_ref(c.evenTextureType, c.evenTextureIdx); d.odd = tex_ref(c.oddTextureType, c.oddTextureIdx); d.pad = 0;
+            out.checker.push_back(d);
+        }
+        for (int i = 0; i < t.num_image_textures; i++) {
+            const mort_image_texture &im = t.host_image_texture[i];
+            DImage d; d.offset = (uint32_t)out.texels.size(); d.width = im.texels ? im.width : 0; d.height = im.texels ? im.height : 0; d.pad = 0;
+            if (im.texels && im.width > 0 && im.height > 0)
+                out.texels.insert(out.texels.end(), im.texels, im.texels + (size_t)im.width * im.height * 3);
+            out.image.push_back(d);
+        }
+        for (int i = 0; i < t.num_noise_textures; i++) {
+            const unsigned char *p = (const unsigned char *)&t.host_noise_texture[i];
+            out.noise.insert(out.noise.end(), p, p + sizeof(mort_noise_texture));
+        }
+    }
+};
+
+} // namespace mortc
+
+#endif
