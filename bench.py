@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Msamples/s on Scene 1 (random-spheres cover),
+1200x675, 500 spp nominal = 484 effective (camera.cuh:51-53), depth 20, one
+MI355X per rank, image rows partitioned across ranks.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full frame through the hot path: mega_kernel over this rank's
+row blocks with RNG states resident in HBM (they persist from frame to frame
+exactly as in the reference's update() loop, mort.cu:93-120), followed, for
+N > 1, by the RCCL gather of the packed uchar4 rows to rank 0 and the
+de-interleave into the full framebuffer.  Seeding (setup_rng) and scene upload
+are outside the timed region, as in the reference (mort.cu:691-725).
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(spp_sample, threads):
+    """Oracle (CPU restatement, oracle/) timed on this box's host cores on a bounded sample of the
+    same workload: Scene 1 at the full 1200x675 geometry, reduced spp."""
+    from mort_amd import host
+    from tests import oracle_lib as O
+    world, cam = host.build_scene(1, spp=spp_sample)
+    states = O.seed_states(69420, cam.image_width, cam.image_height)
+    t0 = time.perf_counter()
+    r = O.render(world, cam, states=states, nthreads=threads, want_accum=False, want_segments=False)
+    dt = time.perf_counter() - t0
+    eff = host.effective_spp(cam)
+    samples = cam.image_width * cam.image_height * eff
+    return {
+        "value": samples / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": f"Scene 1 1200x675 at {spp_sample} spp ({eff} effective), depth 20: {samples} samples, "
+                  f"{r['segments']} segments in {dt:.2f} s on {threads} host threads (C oracle, oracle/mort_oracle.c)",
+        "seconds": dt, "segments": r["segments"],
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=500)
+    ap.add_argument("--width", type=int, default=1200)
+    ap.add_argument("--scene", type=int, default=1)
+    ap.add_argument("--rows-per-block", type=int, default=8)
+    ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")
+    args = ap.parse_args()
+
+    import torch
+    from mort_amd import host, hip
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world_size}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the render path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    # ---- scene, upload, seed (outside the timed region) ----
+    world, cam = host.build_scene(args.scene, width=args.width, spp=args.spp)
+    W, H = cam.image_width, cam.image_height
+    eff = host.effective_spp(cam)
+    ctx = hip.Context(local_rank)
+    ctx.set_partition(rank, world_size, args.rows_per_block)
+    ctx.upload_world(world)
+    ctx.rng_seed(69420, W, H)
+    lr = ctx.local_rows(H)
+    nblocks = (H + args.rows_per_block - 1) // args.rows_per_block
+    max_lr = ((nblocks + world_size - 1) // world_size) * args.rows_per_block
+    tile = torch.zeros((max_lr, W, 4), dtype=torch.uint8, device=dev)  # packed owned rows (padded to equal size)
+    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
+    gathered = None
+    row_index = None
+    if world_size > 1 and rank == 0:
+        gathered = [torch.empty_like(tile) for _ in range(world_size)]
+        # global row of (rank r, local row l): block (l // rpb) * N + r
+        rpb = args.rows_per_block
+        l = torch.arange(max_lr, device=dev)
+        row_index = []
+        for r in range(world_size):
+            g = ((l // rpb) * world_size + r) * rpb + (l % rpb)
+            row_index.append(g)
+
+    # a non-default torch stream: its handle is what the C ABI launches on, and torch.cuda.Event /
+    # torch.distributed both follow torch's *current* stream, so everything below runs under it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ev_pairs = []
+
+    def step(record):
+        e0 = e1 = None
+        if record:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+        # the kernel is launched on torch's current stream, so these events bracket it
+        ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, sync=False)
+        if record:
+            e1.record(stream)
+            ev_pairs.append((e0, e1))
+        if world_size > 1:
+            dist.gather(tile, gathered if rank == 0 else None, dst=0)
+            if rank == 0:
+                for r in range(world_size):
+                    valid = row_index[r] < H
+                    frame.index_copy_(0, row_index[r][valid], gathered[r][valid])
+        # N == 1: `tile` already is the full framebuffer (rank 0 owns every row)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world_size > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step(False)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    kernel_ms = [a.elapsed_time(b) for a, b in ev_pairs]
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t.item())
+
+    # one more frame through the blocking entry to read the library's own counters/HIP-event time
+    st = ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, sync=True)
+
+    if rank == 0:
+        samples_per_step = W * H * eff
+        value = samples_per_step * args.steps / elapsed_max / 1e6
+        avg_kernel_s = (sum(kernel_ms) / max(len(kernel_ms), 1)) * 1e-3
+        pixels_launch = W * lr
+        algo_bytes = 100 * pixels_launch  # 48 B state in + 48 B out + 4 B uchar4 per pixel; 0 B per segment
+        achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        out = {
+            "metric": "Msamples/sec (width x height x spp/s), Scene 1 1200x675",
+            "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Scene {args.scene} (random-spheres cover) {W}x{H}, {args.spp} spp nominal = {eff} effective, "
+                                   f"depth {cam.bounce_limit}, megakernel, seed 69420, host LCG scene",
+                       "mode": "mega", "partition": f"rows/{args.rows_per_block} interleaved over {world_size} rank(s)",
+                       "nominal_msamples_per_s": W * H * args.spp * args.steps / elapsed_max / 1e6},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mega_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
+                                 "so the HBM fraction is tiny and the kernel is VALU/latency bound (DESIGN.md)"},
+            "kernel": {"segments_per_frame": st["segments"], "segments_per_s": st["segments"] / st["seconds"],
+                       "hip_event_seconds": st["seconds"], "vgprs": st["kernel_vgprs"], "lds_bytes": st["kernel_lds_bytes"]},
+        }
+        if world_size == 1 and args.cpu_spp > 0:
+            threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)  # 16 = one GPU's CPU share
+            out["cpu_baseline"] = cpu_baseline(args.cpu_spp, threads)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
