@@ -1,0 +1,400 @@
+/*
+ * mega_bvh.h -- the hot kernel for BVH scenes (Scene 1, Scene 10): world =
+ * one non-skip BVH over spheres, bvh_mode, no light object.
+ *
+ * CDNA4 design (each point bit-identical to the reference's arithmetic):
+ *
+ *  - Scene in LDS.  The whole "hot blob" (threaded BVH nodes, spheres,
+ *    material and texture tables, ~46 KB for Scene 1) is copied into LDS once
+ *    per workgroup; every traversal step reads one 32-byte node or sphere with
+ *    two ds_read_b128.  The reference reads 4 SoA arrays + a 24-byte aabb from
+ *    global memory per node (objects.cuh:728-731).
+ *
+ *  - Per-lane state machine, wave-level scheduling.  Each lane owns one pixel
+ *    and is in one of three states: T (at a BVH node, box test pending),
+ *    L (inside a leaf, sphere tests pending), S (closest hit known: shade,
+ *    scatter, or finish the sample / pixel and start the next ray).  Each
+ *    iteration of the wave's loop runs ONE state's code, chosen from the
+ *    ballot/popcount of the lanes in each state, for the lanes in that state.
+ *    A lane whose path or pixel ends never waits for the wave's longest path
+ *    (the reference's loop nest, camera.cuh:96-159,187-192, runs every lane in
+ *    lockstep with the slowest).
+ *
+ *  - Dynamic pixels.  Lanes fetch pixels from one atomic counter in 8x8-tile
+ *    order (one atomicAdd per wave per refill, lanes ranked by mbcnt), so the
+ *    chip stays full until the pool is empty.
+ *
+ *  - aabb::hit (aabb.cuh:37-59) per node: the fp64 reciprocals are per ray;
+ *    `if (t0 > t_min) t_min = t0` on a float t_min is max(t_min, (float)t0)
+ *    (rounding is monotonic; a NaN t0 leaves t_min unchanged, as v_max_f32
+ *    does), the per-axis early-outs are equivalent to one final compare, and
+ *    the near/far swap is a select on the sign of 1/dir.
+ *
+ *  - Hit record rebuilt only for the winner; sphere uv (acosf/atan2f) only when
+ *    the material's texture reads it.
+ */
+#ifndef MORT_MEGA_BVH_H
+#define MORT_MEGA_BVH_H
+
+#include "dev_trace.h"
+
+struct FastArgs {
+    RenderArgs r;
+    const unsigned char *hot_src; /* device copy of the hot blob */
+    uint32_t hot_bytes;
+    uint32_t off_nodes, off_spheres, off_lambert, off_metal, off_diel, off_dlight, off_iso, off_solid, off_checker;
+    int node_first, node_count;
+    unsigned int *next_q; /* work counter, zeroed before launch */
+    int tiles_x, tiles_total;
+};
+
+enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
+enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
+
+#ifndef MORT_TH_S
+#define MORT_TH_S 16
+#endif
+#ifndef MORT_TH_L
+#define MORT_TH_L 24
+#endif
+#ifndef MORT_T_KEEP
+#define MORT_T_KEEP 40
+#endif
+
+#ifndef MORT_MIN_WAVES
+#define MORT_MIN_WAVES 2
+#endif
+
+template <int BLOCK, int TH_S, int TH_L, int T_KEEP>
+__global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const RenderArgs &a = fa.r;
+    {
+        const uint4 *src = (const uint4 *)fa.hot_src;
+        uint4 *dst = (uint4 *)lds;
+        const uint32_t n16 = fa.hot_bytes >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const DBvhNode *nodes = (const DBvhNode *)(lds + fa.off_nodes);
+    const DSphere *spheres = (const DSphere *)(lds + fa.off_spheres);
+    const DLambert *lambert = (const DLambert *)(lds + fa.off_lambert);
+    const DMetal *metal = (const DMetal *)(lds + fa.off_metal);
+    const DDielectric *dielectric = (const DDielectric *)(lds + fa.off_diel);
+    const DLambert *dlight = (const DLambert *)(lds + fa.off_dlight);
+    const DLambert *isotropic = (const DLambert *)(lds + fa.off_iso);
+    const DSolid *solid = (const DSolid *)(lds + fa.off_solid);
+    const DChecker *checker = (const DChecker *)(lds + fa.off_checker);
+
+    const int node_first = fa.node_first, node_end = fa.node_first + fa.node_count;
+    const int spp = a.sqrt_spp * a.sqrt_spp;
+    const unsigned total_q = (unsigned)fa.tiles_total * 64u;
+
+    /* per-lane state */
+    int state = ST_S, kind = K_NEWPIX;
+    int x = 0, y = 0, lofs = 0;
+    Rng rng; rng.d = rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = 0; rng.draws = 0;
+    V3 pixel_color = mk(0, 0, 0);
+    int s = 0, s_i = 0, s_j = 0, iter = 0;
+    uint32_t segments = 0;
+    Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.tm = 0;
+    float ray_time0 = 0;
+    double inv_x = 0, inv_y = 0, inv_z = 0;
+    float ray_a = 1, closest = 0;
+    int best = -1, node = 0;
+    uint32_t leaf_prims = 0;
+    V3 final_value = mk(0, 0, 0);
+    unsigned long long tot_segments = 0, tot_draws = 0;
+    StackEntry stack[MORT_MAX_BOUNCE_LIMIT];
+#ifdef MORT_PROFILE_STATES
+    unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}; /* steps/lanes for T, L, S (wave-uniform) */
+    unsigned long long profc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* cycles in T, L, S, scheduler; S parts: shade, finish, newpix, setup */
+    unsigned long long ps0 = 0, ps1;
+#define PROFS0() do { ps0 = __builtin_readcyclecounter(); } while (0)
+#define PROFS(i) do { ps1 = __builtin_readcyclecounter(); profc[i] += ps1 - ps0; ps0 = ps1; } while (0)
+    unsigned long long pt0 = __builtin_readcyclecounter(), pt1;
+#define PROF(i, lanes) do { prof[2 * (i)] += 1; prof[2 * (i) + 1] += (unsigned long long)(lanes); } while (0)
+#define PROFC(i) do { pt1 = __builtin_readcyclecounter(); profc[i] += pt1 - pt0; pt0 = pt1; } while (0)
+#else
+#define PROF(i, lanes) do { } while (0)
+#define PROFC(i) do { } while (0)
+#define PROFS0() do { } while (0)
+#define PROFS(i) do { } while (0)
+#endif
+
+    for (;;) {
+        const unsigned long long mT = __ballot(state == ST_T);
+        const unsigned long long mL = __ballot(state == ST_L);
+        const unsigned long long mS = __ballot(state == ST_S);
+        if ((mT | mL | mS) == 0ull) break;
+        const int nT = __popcll(mT), nL = __popcll(mL), nS = __popcll(mS);
+        int pick;
+        if (nS >= TH_S) pick = ST_S;
+        else if (nL >= TH_L) pick = ST_L;
+        else if (nT > 0) pick = ST_T;
+        else pick = (nL >= nS) ? ST_L : ST_S;
+        PROFC(3);
+
+        if (pick == ST_T) {
+            /* ---- box steps (aabb::hit + one move of the threaded walk) ---- */
+            int keep;
+            do {
+                PROF(0, __popcll(__ballot(state == ST_T)));
+                if (state == ST_T) {
+                    const DBvhNode nd = nodes[node];
+                    const bool nx = inv_x < 0, ny = inv_y < 0, nz = inv_z < 0;
+                    const float x0 = nx ? nd.xmax : nd.xmin, x1 = nx ? nd.xmin : nd.xmax;
+                    const float y0 = ny ? nd.ymax : nd.ymin, y1 = ny ? nd.ymin : nd.ymax;
+                    const float z0 = nz ? nd.zmax : nd.zmin, z1 = nz ? nd.zmin : nd.zmax;
+                    float t_min = 0.001f, t_max = closest;
+                    t_min = __builtin_fmaxf(t_min, (float)((double)(x0 - ray.o.x) * inv_x));
+                    t_max = __builtin_fminf(t_max, (float)((double)(x1 - ray.o.x) * inv_x));
+                    t_min = __builtin_fmaxf(t_min, (float)((double)(y0 - ray.o.y) * inv_y));
+                    t_max = __builtin_fminf(t_max, (float)((double)(y1 - ray.o.y) * inv_y));
+                    t_min = __builtin_fmaxf(t_min, (float)((double)(z0 - ray.o.z) * inv_z));
+                    t_max = __builtin_fminf(t_max, (float)((double)(z1 - ray.o.z) * inv_z));
+                    const bool miss = (t_max <= t_min);
+                    const int skip = (int)(nd.skip & 0x7fffffffu);
+                    if (miss) {
+                        node = skip;
+                    } else if (nd.skip >> 31) {
+                        leaf_prims = nd.prims;
+                        node = skip;
+                        state = ST_L;
+                    } else {
+                        node = node + 1;
+                    }
+                    if (state == ST_T && node >= node_end) { state = ST_S; kind = K_SHADE; }
+                }
+                keep = __popcll(__ballot(state == ST_T));
+            } while (keep >= T_KEEP);
+            PROFC(0);
+        } else if (pick == ST_L) {
+            /* ---- leaf: sphere::hit on one or two spheres (objects.cuh:60-77,690-692) ---- */
+            PROF(1, nL);
+            if (state == ST_L) {
+                const uint32_t pa = leaf_prims & 0x7fffu, pb = (leaf_prims >> 16) & 0x7fffu;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t p = k ? pb : pa;
+                    if (k == 1 && pb == pa) break;
+                    const DSphere sp = spheres[p];
+                    float t;
+                    if (sphere_hit_t(sp, ray, ray_a, 0.001f, closest, t)) { closest = t; best = (int)p; }
+                }
+                if (node >= node_end) { state = ST_S; kind = K_SHADE; } else state = ST_T;
+            }
+            PROFC(1);
+        } else {
+            /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
+            PROF(2, nS);
+            PROFS0();
+            if (state == ST_S) {
+                if (kind == K_SHADE) {
+                    if (best < 0) { /* camera.cuh:154-158 */
+                        final_value = a.background;
+                        kind = K_FINISH;
+                    } else {
+                        const DSphere sp = spheres[best];
+                        const V3 p = ray_at(ray, closest);
+                        const V3 outward = vdiv(vsub(p, sphere_center(sp, ray.tm)), sp.radius);
+                        const bool front_face = vdot(ray.d, outward) < 0;
+                        const V3 normal = front_face ? outward : vneg(outward);
+                        const int mtype = DREF_TYPE(sp.mat), midx = DREF_IDX(sp.mat);
+                        StackEntry e;
+                        if (mtype == MORT_MAT_METAL) { /* materials.cuh:73-84 */
+                            const DMetal m = metal[midx];
+                            V3 reflected = reflect(ray.d, normal);
+                            reflected = vadd(vunit(reflected), vscale(m.fuzz, random_unit_vector(rng)));
+                            ray.o = p; ray.d = reflected;
+                            e.kx = 1.0f * m.r; e.ky = 1.0f * m.g; e.kz = 1.0f * m.b; e.rp = 1.0f;
+                        } else if (mtype == MORT_MAT_DIELECTRIC) { /* materials.cuh:107-130 */
+                            const DDielectric m = dielectric[midx];
+                            const float refraction_ratio = front_face ? m.inv_ior : m.ior;
+                            const V3 unit_direction = vunit(ray.d);
+                            const float cos_theta = (float)mort_fmin((double)vdot(vneg(unit_direction), normal), 1.0);
+                            const float sin_theta = (float)mort_sqrt(1.0 - (double)(cos_theta * cos_theta));
+                            const bool cant_refract = (double)(refraction_ratio * sin_theta) > 1.0;
+                            V3 direction;
+                            if (cant_refract || reflectance(cos_theta, refraction_ratio) > random_float(rng))
+                                direction = reflect(unit_direction, normal);
+                            else
+                                direction = refract(unit_direction, normal, refraction_ratio);
+                            ray.o = p; ray.d = direction;
+                            e.kx = 1.0f; e.ky = 1.0f; e.kz = 1.0f; e.rp = 1.0f;
+                        } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
+                            const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
+                            const DLambert m = lamb ? lambert[midx] : isotropic[midx];
+                            V3 attenuation = mk(m.r, m.g, m.b);
+                            if (m.tex != 0) {
+                                uint32_t tex = m.tex;
+                                bool resolved = false;
+                                for (int guard = 0; guard < 8 && !resolved; guard++) {
+                                    const int tt = DREF_TYPE(tex), ti = DREF_IDX(tex);
+                                    if (tt == MORT_TEXTURE_SOLID) { const DSolid sc = solid[ti]; attenuation = mk(sc.r, sc.g, sc.b); resolved = true; }
+                                    else if (tt == MORT_TEXTURE_CHECKER) {
+                                        const DChecker c = checker[ti];
+                                        const int xi = mort_f2i(mort_floorf(c.inv_scale * p.x));
+                                        const int yi = mort_f2i(mort_floorf(c.inv_scale * p.y));
+                                        const int zi = mort_f2i(mort_floorf(c.inv_scale * p.z));
+                                        tex = ((xi + yi + zi) % 2 == 0) ? c.even : c.odd;
+                                    } else break;
+                                }
+                                if (!resolved) { /* image / noise / error pattern: tables stay in HBM */
+                                    float u, v;
+                                    sphere_uv(outward, u, v);
+                                    attenuation = texture_value(a.sc, tex, u, v, p);
+                                }
+                            }
+                            V3 dir;
+                            float mat_pdf, scattering_pdf;
+                            if (lamb) {
+                                const Onb uvw = onb_from_w(normal);
+                                dir = onb_local(uvw, random_cosine_direction(rng));
+                                const V3 ud = vunit(dir);
+                                const float cosine_theta = vdot(ud, uvw.w);
+                                mat_pdf = mort_fmaxf(0, (float)((double)cosine_theta / 3.1415926));
+                                const float cos_theta = vdot(normal, ud);
+                                scattering_pdf = (cos_theta < 0) ? 0.0f : (float)((double)cos_theta / 3.141592565);
+                            } else {
+                                dir = random_unit_vector(rng);
+                                mat_pdf = (float)(1 / (4 * 3.1415926));
+                                scattering_pdf = (float)(1 / (4 * 3.1415926));
+                            }
+                            ray.o = p; ray.d = dir; ray.tm = ray_time0;
+                            e.kx = scattering_pdf * attenuation.x; e.ky = scattering_pdf * attenuation.y; e.kz = scattering_pdf * attenuation.z;
+                            e.rp = 1 / mat_pdf;
+                        } else { /* diffuse_light or unknown tag: no scatter (materials.cuh:151-163) */
+                            V3 emission = mk(0, 0, 0);
+                            if (mtype == MORT_MAT_DIFFUSE_LIGHT && front_face) {
+                                const DLambert m = dlight[midx];
+                                if (m.tex == 0) emission = mk(m.r, m.g, m.b);
+                                else { float u, v; sphere_uv(outward, u, v); emission = texture_value(a.sc, m.tex, u, v, p); }
+                            }
+                            final_value = emission;
+                            kind = K_FINISH;
+                        }
+                        if (kind == K_SHADE) {
+                            stack[iter] = e;
+                            iter++;
+                            if (iter >= a.bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
+                        }
+                    }
+                }
+                PROFS(4);
+                if (kind == K_FINISH) { /* unwind + accumulate (camera.cuh:165-173,190) */
+                    while (iter > 0) {
+                        iter--;
+                        const StackEntry e = stack[iter];
+                        const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
+                        final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
+                    }
+                    pixel_color = vadd(pixel_color, final_value);
+                    s++;
+                    s_i++;
+                    if (s_i == a.sqrt_spp) { s_i = 0; s_j++; }
+                    if (s < spp) {
+                        kind = K_NEWSAMPLE;
+                    } else { /* camera.cuh:194-207 */
+                        V3 c = vscale(a.pixel_samples_scale, pixel_color);
+                        if (c.x != c.x) c.x = 0.0f;
+                        if (c.y != c.y) c.y = 0.0f;
+                        if (c.z != c.z) c.z = 0.0f;
+                        if (a.accum) { a.accum[3 * lofs] = c.x; a.accum[3 * lofs + 1] = c.y; a.accum[3 * lofs + 2] = c.z; }
+                        float g[3] = {mort_sqrtf(c.x), mort_sqrtf(c.y), mort_sqrtf(c.z)};
+                        unsigned char b[3];
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            float v = g[k];
+                            if (v < 0.0f) v = 0.0f;
+                            if (v > 0.999f) v = 0.999f;
+                            b[k] = (unsigned char)mort_f2i(256 * v);
+                        }
+                        uchar4 out; out.x = b[0]; out.y = b[1]; out.z = b[2]; out.w = 255;
+                        a.rgba[lofs] = out;
+                        if (a.seg_px) a.seg_px[lofs] = segments;
+                        mort_rng_state st;
+                        st.d = rng.d; st.v[0] = rng.v0; st.v[1] = rng.v1; st.v[2] = rng.v2; st.v[3] = rng.v3; st.v[4] = rng.v4;
+                        st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
+                        a.states[lofs] = st;
+                        tot_segments += segments; tot_draws += rng.draws;
+                        kind = K_NEWPIX;
+                    }
+                }
+                PROFS(5);
+                if (kind == K_NEWPIX) {
+                    /* one atomicAdd per wave per refill; lanes take consecutive slots in 8x8-tile order */
+                    bool got = false;
+                    while (!got) {
+                        const unsigned long long need = __ballot(1);
+                        const int cnt = __popcll(need);
+                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+                        unsigned base = 0;
+                        if (rank == 0) base = atomicAdd(fa.next_q, (unsigned)cnt);
+                        base = __shfl(base, __ffsll((long long)need) - 1);
+                        const unsigned q = base + (unsigned)rank;
+                        if (q >= total_q) { state = ST_DONE; got = true; break; }
+                        const int tile = (int)(q >> 6), within = (int)(q & 63u);
+                        const int tx = tile % fa.tiles_x, ty = tile / fa.tiles_x;
+                        const int qx = tx * 8 + (within & 7), qly = ty * 8 + (within >> 3);
+                        if (qx < a.width && qly < a.local_rows) {
+                            x = qx;
+                            y = global_row(qly, a.rank, a.nranks, a.rows_per_block);
+                            lofs = qx + qly * a.width;
+                            got = true;
+                        }
+                    }
+                    if (state != ST_DONE) {
+                        const mort_rng_state st = a.states[lofs];
+                        rng.d = st.d; rng.v0 = st.v[0]; rng.v1 = st.v[1]; rng.v2 = st.v[2]; rng.v3 = st.v[3]; rng.v4 = st.v[4];
+                        rng.draws = 0;
+                        pixel_color = mk(0, 0, 0);
+                        s = 0; s_i = 0; s_j = 0; segments = 0;
+                        kind = (spp > 0) ? K_NEWSAMPLE : K_FINISH;
+                        if (spp <= 0) { /* degenerate: zero samples -> 0 * inf = NaN -> 0 */
+                            final_value = mk(0, 0, 0);
+                        }
+                    }
+                }
+                PROFS(6);
+                if (state != ST_DONE) {
+                    if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
+                        ray = get_ray(a, x, y, rng, s_i, s_j);
+                        ray_time0 = ray.tm;
+                        iter = 0;
+                        kind = K_SHADE;
+                        if (a.bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
+                    }
+                    if (kind == K_SHADE) { /* start world::hit for the new ray */
+                        inv_x = 1.0 / (double)ray.d.x; inv_y = 1.0 / (double)ray.d.y; inv_z = 1.0 / (double)ray.d.z;
+                        ray_a = vlen2(ray.d);
+                        closest = __builtin_inff();
+                        best = -1;
+                        node = node_first;
+                        segments++;
+                        state = (node < node_end) ? ST_T : ST_S;
+                    }
+                    /* kind == K_FINISH here (bounce_limit 0 or spp 0): stays in ST_S for the next S step */
+                }
+            }
+            PROFS(7);
+            PROFC(2);
+        }
+    }
+    /* per-wave totals */
+    for (int off = 32; off > 0; off >>= 1) {
+        tot_segments += __shfl_down(tot_segments, off);
+        tot_draws += __shfl_down(tot_draws, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&a.counters[0], tot_segments);
+        atomicAdd(&a.counters[1], tot_draws);
+#ifdef MORT_PROFILE_STATES
+        for (int k = 0; k < 6; k++) atomicAdd(&a.counters[4 + k], prof[k]);
+        for (int k = 0; k < 4; k++) atomicAdd(&a.counters[10 + k], profc[k]);
+        for (int k = 4; k < 8; k++) atomicAdd(&a.counters[14 + k - 4], profc[k]);
+#endif
+    }
+}
+
+#endif

@@ -326,6 +326,8 @@ seed_kernel(const SeedArgs a) {
     a.states[i] = st;
 }
 
+#include "mega_bvh.h"
+
 /* ====================================================================== host */
 
 #define SEQ_LEVELS 32
@@ -351,7 +353,12 @@ struct mort_ctx {
     /* scratch */
     void *d_rgba = nullptr, *d_accum = nullptr, *d_segpx = nullptr;
     size_t rgba_cap = 0, accum_cap = 0, segpx_cap = 0;
-    unsigned long long *d_counters = nullptr;
+    unsigned long long *d_counters = nullptr; /* [0] segments, [1] rng draws, [2] work counter */
+    /* fast (BVH-in-LDS) kernel: offsets of the tables inside the hot blob */
+    uint32_t off_nodes = 0, off_spheres = 0, off_lambert = 0, off_metal = 0, off_diel = 0, off_dlight = 0, off_iso = 0,
+             off_solid = 0, off_checker = 0, hot_bytes = 0;
+    bool fast_ok = false;
+    int num_cus = 256;
 };
 
 static int hip_fail(mort_ctx *c, hipError_t e, const char *what) {
@@ -434,9 +441,10 @@ extern "C" int mort_hip_init(int device, mort_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete c; return MORT_ERR_NO_DEVICE; }
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) { delete c; return MORT_ERR_NO_DEVICE; }
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc(&c->d_counters, 2 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&c->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess) {
         mort_hip_shutdown(c);
         return MORT_ERR_HIP;
     }
@@ -565,6 +573,11 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     c->list_types = o.list_types; c->list_idxs = o.list_idxs;
     for (int i = 0; i < MORT_NUM_HITTABLE_LIST; i++) { c->list_first[i] = o.list_first[i]; c->list_count[i] = o.list_count[i]; }
     c->n_wspheres = (int)o.wspheres.size(); c->n_wquads = (int)o.wquads.size(); c->n_lists = w->objs.num_hittable_list;
+    c->off_nodes = (uint32_t)o_nodes; c->off_spheres = (uint32_t)o_sph; c->off_lambert = (uint32_t)o_lamb;
+    c->off_metal = (uint32_t)o_metal; c->off_diel = (uint32_t)o_diel; c->off_dlight = (uint32_t)o_dl; c->off_iso = (uint32_t)o_iso;
+    c->off_solid = (uint32_t)o_solid; c->off_checker = (uint32_t)o_chk; c->hot_bytes = (uint32_t)hot_bytes;
+    /* the LDS state-machine kernel handles: one BVH over spheres as the whole world */
+    c->fast_ok = (o.items.size() == 1 && o.items[0].kind == ITEM_BVH && o.quads.empty() && hot_bytes <= 64 * 1024);
     c->have_world = true;
     return MORT_OK;
 }
@@ -687,12 +700,31 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     a.rgba = (uchar4 *)d_rgba; a.accum = (float *)d_accum; a.seg_px = (uint32_t *)c->d_segpx;
     a.counters = c->d_counters;
 
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 2 * sizeof(unsigned long long), s));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), s));
     const int tiles = ((W + 7) / 8) * ((a.local_rows + 7) / 8);
     const int waves_per_block = 4;
     const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
+    const char *force = std::getenv("MORT_FORCE_GENERIC");
+    const bool use_fast = c->fast_ok && cam->light_obj_type == -1 && !(force && force[0] == '1');
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
-    if (blocks > 0) {
+    if (blocks > 0 && use_fast) {
+        FastArgs fa;
+        std::memset(&fa, 0, sizeof fa);
+        fa.r = a;
+        fa.hot_src = (const unsigned char *)c->d_scene; fa.hot_bytes = c->hot_bytes;
+        fa.off_nodes = c->off_nodes; fa.off_spheres = c->off_spheres; fa.off_lambert = c->off_lambert; fa.off_metal = c->off_metal;
+        fa.off_diel = c->off_diel; fa.off_dlight = c->off_dlight; fa.off_iso = c->off_iso; fa.off_solid = c->off_solid; fa.off_checker = c->off_checker;
+        fa.node_first = 0; fa.node_count = c->sc.n_nodes;
+        fa.next_q = (unsigned int *)(c->d_counters + 2);
+        fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
+        auto kern = mega_bvh_kernel<256, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, c->hot_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+        int grid = c->num_cus * per_cu;
+        if (grid > blocks) grid = blocks;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), c->hot_bytes, s, fa);
+        HIPCHK(c, hipGetLastError());
+    } else if (blocks > 0) {
         hipLaunchKernelGGL(mega_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, s, a);
         HIPCHK(c, hipGetLastError());
     }
@@ -701,8 +733,22 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         HIPCHK(c, hipEventSynchronize(c->ev1));
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        unsigned long long cnt[2] = {0, 0};
+        unsigned long long cnt[32] = {0};
         HIPCHK(c, hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
+#ifdef MORT_PROFILE_STATES
+        {
+            const char *nm[3] = {"T", "L", "S"};
+            for (int k = 0; k < 3; k++)
+                std::fprintf(stderr, "[states] %s: %llu wave-steps, %llu lane-steps, utilisation %.1f%%\n", nm[k], cnt[4 + 2 * k], cnt[5 + 2 * k],
+                             cnt[4 + 2 * k] ? 100.0 * (double)cnt[5 + 2 * k] / (64.0 * (double)cnt[4 + 2 * k]) : 0.0);
+            const double tot = (double)(cnt[10] + cnt[11] + cnt[12] + cnt[13]);
+            std::fprintf(stderr, "[cycles] T %.1f%% (%.0f/step)  L %.1f%% (%.0f/step)  S %.1f%% (%.0f/step)  sched %.1f%%  total wave-cycles %.3g\n",
+                         100.0 * cnt[10] / tot, (double)cnt[10] / (double)cnt[4], 100.0 * cnt[11] / tot, (double)cnt[11] / (double)cnt[6],
+                         100.0 * cnt[12] / tot, (double)cnt[12] / (double)cnt[8], 100.0 * cnt[13] / tot, tot);
+            std::fprintf(stderr, "[S parts, cycles/step] shade %.0f  finish %.0f  newpix %.0f  newsample+setup %.0f\n", (double)cnt[14] / (double)cnt[8],
+                         (double)cnt[15] / (double)cnt[8], (double)cnt[16] / (double)cnt[8], (double)cnt[17] / (double)cnt[8]);
+        }
+#endif
         std::memset(stats, 0, sizeof *stats);
         stats->seconds = ms * 1e-3;
         stats->segments = cnt[0];
@@ -710,12 +756,13 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         stats->pixels = (uint64_t)W * (uint64_t)a.local_rows;
         stats->eff_samples = stats->pixels * (uint64_t)(cam->sqrt_spp * cam->sqrt_spp);
         stats->algorithmic_hbm_bytes = stats->pixels * (uint64_t)(100 + (d_accum ? 12 : 0));
-        stats->scene_in_lds = 0;
+        stats->scene_in_lds = use_fast ? 1 : 0;
         stats->local_rows = a.local_rows;
-        hipFuncAttributes fa;
-        if (hipFuncGetAttributes(&fa, (const void *)mega_kernel) == hipSuccess) {
-            stats->kernel_vgprs = fa.numRegs;
-            stats->kernel_lds_bytes = (int)fa.sharedSizeBytes;
+        hipFuncAttributes fattr;
+        const void *kf = use_fast ? (const void *)mega_bvh_kernel<256, MORT_TH_S, MORT_TH_L, MORT_T_KEEP> : (const void *)mega_kernel;
+        if (hipFuncGetAttributes(&fattr, kf) == hipSuccess) {
+            stats->kernel_vgprs = fattr.numRegs;
+            stats->kernel_lds_bytes = use_fast ? (int)c->hot_bytes : (int)fattr.sharedSizeBytes;
         }
     }
     return MORT_OK;
