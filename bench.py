@@ -17,7 +17,6 @@ are outside the timed region, as in the reference (mort.cu:691-725).
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -63,7 +62,7 @@ def main():
     args = ap.parse_args()
 
     import torch
-    from mort_amd import host, hip
+    from mort_amd import host, hip, partition
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -91,21 +90,8 @@ def main():
     ctx.upload_world(world)
     ctx.rng_seed(69420, W, H)
     lr = ctx.local_rows(H)
-    nblocks = (H + args.rows_per_block - 1) // args.rows_per_block
-    max_lr = ((nblocks + world_size - 1) // world_size) * args.rows_per_block
-    tile = torch.zeros((max_lr, W, 4), dtype=torch.uint8, device=dev)  # packed owned rows (padded to equal size)
-    frame = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev) if rank == 0 else None
-    gathered = None
-    row_index = None
-    if world_size > 1 and rank == 0:
-        gathered = [torch.empty_like(tile) for _ in range(world_size)]
-        # global row of (rank r, local row l): block (l // rpb) * N + r
-        rpb = args.rows_per_block
-        l = torch.arange(max_lr, device=dev)
-        row_index = []
-        for r in range(world_size):
-            g = ((l // rpb) * world_size + r) * rpb + (l % rpb)
-            row_index.append(g)
+    fg = partition.FrameGather(H, W, 4, torch.uint8, rank, world_size, args.rows_per_block, dev)
+    tile = fg.tile  # packed owned rows (padded so every rank's tile has the same shape)
 
     # a non-default torch stream: its handle is what the C ABI launches on, and torch.cuda.Event /
     # torch.distributed both follow torch's *current* stream, so everything below runs under it
@@ -126,11 +112,7 @@ def main():
             e1.record(stream)
             ev_pairs.append((e0, e1))
         if world_size > 1:
-            dist.gather(tile, gathered if rank == 0 else None, dst=0)
-            if rank == 0:
-                for r in range(world_size):
-                    valid = row_index[r] < H
-                    frame.index_copy_(0, row_index[r][valid], gathered[r][valid])
+            fg.gather(dist)  # RCCL gather of the packed uchar4 rows + de-interleave on rank 0
         # N == 1: `tile` already is the full framebuffer (rank 0 owns every row)
 
     def sync_all():

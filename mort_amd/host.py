@@ -111,6 +111,17 @@ def synthetic_earth(width=1024, height=512):
     return np.ascontiguousarray(np.stack([r, g, b], axis=-1))
 
 
+_EARTH_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap_rgb.npz")
+
+
+def load_earth():
+    """Texels of the reference's imgs/earthmap.jpg as decoded by its vendored stb_image.h
+    (fixture made by oracle/_ref/stb_decode, tests/golden/make_golden.py); synthetic stand-in if absent."""
+    if os.path.exists(_EARTH_FIXTURE):
+        return np.ascontiguousarray(np.load(_EARTH_FIXTURE)["rgb"])
+    return synthetic_earth()
+
+
 def build_scene(scene_id, width=None, spp=None, depth=None, aspect=None, args_rtl=0, earth=None):
     """mort <scene_id> plus the CLI overrides. Returns (World, Camera) with the camera initialised.
 
@@ -121,7 +132,7 @@ def build_scene(scene_id, width=None, spp=None, depth=None, aspect=None, args_rt
     opts.args_rtl = args_rtl
     if scene_id in (3, 8, 9):
         if earth is None:
-            earth = synthetic_earth()
+            earth = load_earth()
         earth = np.ascontiguousarray(earth, dtype=np.uint8)
         w._keepalive.append(earth)
         opts.earth_texels = earth.ctypes.data
