@@ -52,17 +52,17 @@ enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
 enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 
 #ifndef MORT_TH_S
-#define MORT_TH_S 16
+#define MORT_TH_S 24
 #endif
 #ifndef MORT_TH_L
 #define MORT_TH_L 24
 #endif
 #ifndef MORT_T_KEEP
-#define MORT_T_KEEP 40
+#define MORT_T_KEEP 24
 #endif
 
 #ifndef MORT_MIN_WAVES
-#define MORT_MIN_WAVES 2
+#define MORT_MIN_WAVES 3
 #endif
 
 template <int BLOCK, int TH_S, int TH_L, int T_KEEP>
