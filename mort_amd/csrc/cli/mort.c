@@ -6,7 +6,7 @@
  *
  *   mort <scene_id> [--width W] [--aspect A] [--spp N] [--depth D] [--seed S]
  *                   [--out file.ppm] [--dump-f32 file.raw] [--states-in f] [--states-out f]
- *                   [--earth file.ppm] [--rtl] [--frames N] [--device K]
+ *                   [--earth file.ppm] [--rtl] [--frames N] [--device K] [--mode mega|wave]
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -27,7 +27,7 @@ int main(int argc, char **argv) {
         return -1;
     }
     int scene = atoi(argv[1]);
-    int width = 0, spp = 0, depth = -1, frames = 1, device = 0, rtl = 0;
+    int width = 0, spp = 0, depth = -1, frames = 1, device = 0, rtl = 0, mode = MORT_MODE_MEGA;
     double aspect = 0;
     unsigned long long seed = MORT_DEFAULT_SEED;
     const char *out = NULL, *dump = NULL, *sin = NULL, *sout = NULL, *earth = "tests/golden/earthmap.ppm";
@@ -45,6 +45,7 @@ int main(int argc, char **argv) {
         else if (ARG("--earth")) earth = argv[++i];
         else if (ARG("--frames")) frames = atoi(argv[++i]);
         else if (ARG("--device")) device = atoi(argv[++i]);
+        else if (ARG("--mode")) { const char *m = argv[++i]; mode = (strcmp(m, "wave") == 0) ? MORT_MODE_WAVE : MORT_MODE_MEGA; }
         else if (strcmp(argv[i], "--rtl") == 0) rtl = 1;
         else { fprintf(stderr, "unknown option %s\n", argv[i]); return -1; }
     }
@@ -89,7 +90,7 @@ int main(int argc, char **argv) {
     double total_ms = 0;
     mort_stats stats;
     for (int f = 0; f < frames; f++) {
-        if ((st = mort_hip_render(ctx, &cam, MORT_MODE_MEGA, rgba, accum, NULL, &stats)) != MORT_OK) die(ctx, st, "mort_hip_render");
+        if ((st = mort_hip_render(ctx, &cam, mode, rgba, accum, NULL, &stats)) != MORT_OK) die(ctx, st, "mort_hip_render");
         total_ms += stats.seconds * 1e3;
         printf("Avg. time per frame: %3.1f ms\n", total_ms / (f + 1)); /* mort.cu:119 */
     }

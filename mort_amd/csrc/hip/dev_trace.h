@@ -132,6 +132,70 @@ DEV bool aabb_hit(const DBvhNode &b, const Ray &r, const InvDir &inv, float t_mi
 }
 #undef SLAB
 
+/* ---- aabb::hit as a BOOLEAN, decided in fp32 whenever that is provably the reference's answer ----
+ *
+ * The reference computes, per plane, a = fl32(plane - orig), t64 = fl64(a * inv64) with
+ * inv64 = fl64(1.0 / dir), narrows t64 to fp32 where it updates t_min / t_max, and reports a miss iff
+ * t_max <= t_min after the three axes (aabb.cuh:37-59; equivalently r = fl32(t64) per plane,
+ * t_min = max(0.001, min(r0,r1) per axis), t_max = min(closest, max(r0,r1) per axis): see mega_bvh.h).
+ * Only that boolean is used.  Let inv32 = fl32(inv64) and p = fl32(a * inv32).  For finite normal values
+ * p / r = (1+e1)(1+e2) / ((1+e3)(1+e4)) with |e1|,|e2|,|e4| <= 2^-24, |e3| <= 2^-53, so |p - r| <= 2^-22 |p|.
+ * max / min are 1-Lipschitz, so |gap_p - gap_r| <= 2 * 2^-22 * M with M = max |p| over the six planes, where
+ * gap = t_max - t_min; the fp32 subtraction adds <= 2^-24 * 2M.  With tau = 2^-20 * M:
+ *     gap_p >  tau  =>  gap_r > 0  (reference: hit)        gap_p < -tau  =>  gap_r < 0  (reference: miss)
+ * and only |gap_p| <= tau (about one box test in 10^5) needs the exact fp64 evaluation.  Rays whose
+ * reciprocal is not a normal finite fp32 (zero / denormal / huge direction components: inf, NaN products)
+ * always take the exact path (`exact_only`).  The result is the reference's boolean in every case.
+ */
+struct SlabRay {
+    float ox, oy, oz;
+    float i32x, i32y, i32z; /* fl32(inv64) */
+    double ix, iy, iz;      /* inv64 = 1.0 / (double)dir */
+    bool exact_only;
+};
+DEV bool slab_inv_ok(float v) { const float a = mort_fabsf(v); return a > 1e-30f && a < 1e30f; }
+DEV SlabRay slab_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
+    SlabRay s;
+    s.ox = ox; s.oy = oy; s.oz = oz;
+    s.ix = 1.0 / (double)dx; s.iy = 1.0 / (double)dy; s.iz = 1.0 / (double)dz;
+    s.i32x = (float)s.ix; s.i32y = (float)s.iy; s.i32z = (float)s.iz;
+    s.exact_only = !(slab_inv_ok(s.i32x) && slab_inv_ok(s.i32y) && slab_inv_ok(s.i32z));
+    return s;
+}
+DEV bool slab_exact(const DBvhNode &nd, float ox, float oy, float oz, double ix, double iy, double iz, float closest) {
+    const bool nx = ix < 0, ny = iy < 0, nz = iz < 0;
+    const float x0 = nx ? nd.xmax : nd.xmin, x1 = nx ? nd.xmin : nd.xmax;
+    const float y0 = ny ? nd.ymax : nd.ymin, y1 = ny ? nd.ymin : nd.ymax;
+    const float z0 = nz ? nd.zmax : nd.zmin, z1 = nz ? nd.zmin : nd.zmax;
+    float t_min = 0.001f, t_max = closest;
+    t_min = __builtin_fmaxf(t_min, (float)((double)(x0 - ox) * ix));
+    t_max = __builtin_fminf(t_max, (float)((double)(x1 - ox) * ix));
+    t_min = __builtin_fmaxf(t_min, (float)((double)(y0 - oy) * iy));
+    t_max = __builtin_fminf(t_max, (float)((double)(y1 - oy) * iy));
+    t_min = __builtin_fmaxf(t_min, (float)((double)(z0 - oz) * iz));
+    t_max = __builtin_fminf(t_max, (float)((double)(z1 - oz) * iz));
+    return !(t_max <= t_min);
+}
+/* returns true when the box is hit (reference: !(t_max <= t_min)) */
+DEV bool slab_hit(const DBvhNode &nd, const SlabRay &r, float closest) {
+    const float px0 = (nd.xmin - r.ox) * r.i32x, px1 = (nd.xmax - r.ox) * r.i32x;
+    const float py0 = (nd.ymin - r.oy) * r.i32y, py1 = (nd.ymax - r.oy) * r.i32y;
+    const float pz0 = (nd.zmin - r.oz) * r.i32z, pz1 = (nd.zmax - r.oz) * r.i32z;
+    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(px0, px1), __builtin_fminf(py0, py1)),
+                                        __builtin_fmaxf(__builtin_fminf(pz0, pz1), 0.001f));
+    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(px0, px1), __builtin_fmaxf(py0, py1)),
+                                        __builtin_fminf(__builtin_fmaxf(pz0, pz1), closest));
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mort_fabsf(px0), mort_fabsf(px1)), __builtin_fmaxf(mort_fabsf(py0), mort_fabsf(py1))),
+                                    __builtin_fmaxf(mort_fabsf(pz0), mort_fabsf(pz1)));
+    const float gap = t_max - t_min;
+    const float tau = m * 9.5367431640625e-07f; /* 2^-20 */
+    /* decided only when everything is finite, away from the denormal range, and outside the error band */
+    const bool decided = !r.exact_only && (mort_fabsf(gap) > tau) && (m < 1e30f) && (m > 1e-30f);
+    bool hit = gap > 0;
+    if (!decided) hit = slab_exact(nd, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, closest);
+    return hit;
+}
+
 /* ---- closest hit over a run of primitives sharing one chain ---- */
 DEV void run_spheres(const DScene &sc, const Ray &rw, int first, int count, int cf, int cc, float t_min, float &closest, Best &best) {
     const Ray r = apply_chain(sc, rw, cf, cc);
@@ -158,7 +222,7 @@ DEV void run_quads(const DScene &sc, const Ray &rw, int first, int count, int cf
 
 /* ---- bvh::hit, threaded (objects.cuh:664-723) ---- */
 DEV void run_bvh(const DScene &sc, const Ray &r, int first, int count, float t_min, float &closest, Best &best) {
-    const InvDir inv = inv_dir(r);
+    const SlabRay sr = slab_ray(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z);
     const float a = vlen2(r.d);
     const int end = first + count;
     int node = first;
@@ -166,7 +230,7 @@ DEV void run_bvh(const DScene &sc, const Ray &r, int first, int count, float t_m
         const DBvhNode nd = sc.nodes[node];
         const bool leaf = nd.skip >> 31;
         const int skip = (int)(nd.skip & 0x7fffffffu);
-        if (!aabb_hit(nd, r, inv, t_min, closest)) { node = skip; continue; }
+        if (!slab_hit(nd, sr, closest)) { node = skip; continue; } /* t_min = 0.001f: the only value world::hit passes */
         if (!leaf) { node = node + 1; continue; }
         const uint32_t pa = nd.prims & 0xffffu, pb = nd.prims >> 16;
 #pragma unroll

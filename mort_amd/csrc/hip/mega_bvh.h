@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
     uint32_t segments = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.tm = 0;
     float ray_time0 = 0;
-    double inv_x = 0, inv_y = 0, inv_z = 0;
+    SlabRay sr = slab_ray(0, 0, 0, 0, 0, 1);
     float ray_a = 1, closest = 0;
     int best = -1, node = 0;
     uint32_t leaf_prims = 0;
@@ -142,18 +142,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                 PROF(0, __popcll(__ballot(state == ST_T)));
                 if (state == ST_T) {
                     const DBvhNode nd = nodes[node];
-                    const bool nx = inv_x < 0, ny = inv_y < 0, nz = inv_z < 0;
-                    const float x0 = nx ? nd.xmax : nd.xmin, x1 = nx ? nd.xmin : nd.xmax;
-                    const float y0 = ny ? nd.ymax : nd.ymin, y1 = ny ? nd.ymin : nd.ymax;
-                    const float z0 = nz ? nd.zmax : nd.zmin, z1 = nz ? nd.zmin : nd.zmax;
-                    float t_min = 0.001f, t_max = closest;
-                    t_min = __builtin_fmaxf(t_min, (float)((double)(x0 - ray.o.x) * inv_x));
-                    t_max = __builtin_fminf(t_max, (float)((double)(x1 - ray.o.x) * inv_x));
-                    t_min = __builtin_fmaxf(t_min, (float)((double)(y0 - ray.o.y) * inv_y));
-                    t_max = __builtin_fminf(t_max, (float)((double)(y1 - ray.o.y) * inv_y));
-                    t_min = __builtin_fmaxf(t_min, (float)((double)(z0 - ray.o.z) * inv_z));
-                    t_max = __builtin_fminf(t_max, (float)((double)(z1 - ray.o.z) * inv_z));
-                    const bool miss = (t_max <= t_min);
+                    const bool miss = !slab_hit(nd, sr, closest); /* aabb::hit (aabb.cuh:37-59), fp32-decided when provable */
                     const int skip = (int)(nd.skip & 0x7fffffffu);
                     if (miss) {
                         node = skip;
@@ -366,7 +355,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         if (a.bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
                     }
                     if (kind == K_SHADE) { /* start world::hit for the new ray */
-                        inv_x = 1.0 / (double)ray.d.x; inv_y = 1.0 / (double)ray.d.y; inv_z = 1.0 / (double)ray.d.z;
+                        sr = slab_ray(ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
                         ray_a = vlen2(ray.d);
                         closest = __builtin_inff();
                         best = -1;

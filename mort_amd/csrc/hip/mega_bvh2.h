@@ -47,6 +47,8 @@ enum { P_DONE = 0, P_FIN = 1, P_SPEC = 2, P_LAMB = 3, P_L = 4, P_T = 5 };
 struct Trav {
     float ox, oy, oz, dx, dy, dz, tm; /* ray; once a path has terminated (P_FIN) dx,dy,dz carry its final value */
     double ix, iy, iz;                /* 1.0 / dir, fp64 (aabb.cuh:40) */
+    float jx, jy, jz;                 /* fl32 of the reciprocals (slab_hit) */
+    int exact_only;
     float a, closest;
     int best;
     uint32_t bmat;
@@ -71,7 +73,7 @@ struct Pix {
 
 DEV void swap_trav(Trav &a, Trav &b) {
     SWAPF(a.ox, b.ox); SWAPF(a.oy, b.oy); SWAPF(a.oz, b.oz); SWAPF(a.dx, b.dx); SWAPF(a.dy, b.dy); SWAPF(a.dz, b.dz); SWAPF(a.tm, b.tm);
-    SWAPD(a.ix, b.ix); SWAPD(a.iy, b.iy); SWAPD(a.iz, b.iz);
+    SWAPD(a.ix, b.ix); SWAPD(a.iy, b.iy); SWAPD(a.iz, b.iz); SWAPF(a.jx, b.jx); SWAPF(a.jy, b.jy); SWAPF(a.jz, b.jz); SWAPI(a.exact_only, b.exact_only);
     SWAPF(a.a, b.a); SWAPF(a.closest, b.closest);
     SWAPI(a.best, b.best); SWAPU(a.bmat, b.bmat); SWAPI(a.node, b.node); SWAPU(a.leaf, b.leaf); SWAPI(a.state, b.state); SWAPI(a.pid, b.pid);
 }
@@ -130,7 +132,7 @@ __global__ void __launch_bounds__(BLOCK, MORT2_MIN_WAVES) mega_bvh2_kernel(const
     const int tid = threadIdx.x;
 
     Trav c, o;
-    c.ox = c.oy = c.oz = 0; c.dx = c.dy = 0; c.dz = 1; c.tm = 0; c.ix = c.iy = c.iz = 1; c.a = 1; c.closest = 0;
+    c.ox = c.oy = c.oz = 0; c.dx = c.dy = 0; c.dz = 1; c.tm = 0; c.ix = c.iy = c.iz = 1; c.jx = c.jy = c.jz = 1; c.exact_only = 0; c.a = 1; c.closest = 0;
     c.best = -1; c.bmat = 0; c.node = 0; c.leaf = 0; c.state = P_FIN; c.pid = 0;
     o = c; o.pid = 1;
     Pix p0, p1;
@@ -156,7 +158,8 @@ __global__ void __launch_bounds__(BLOCK, MORT2_MIN_WAVES) mega_bvh2_kernel(const
 
     /* start world::hit for the ray in c (world.cuh:104-120: one BVH, bvh_mode) */
 #define BEGIN_TRAVERSAL(P) do { \
-        c.ix = 1.0 / (double)c.dx; c.iy = 1.0 / (double)c.dy; c.iz = 1.0 / (double)c.dz; \
+        { const SlabRay sr_ = slab_ray(c.ox, c.oy, c.oz, c.dx, c.dy, c.dz); c.ix = sr_.ix; c.iy = sr_.iy; c.iz = sr_.iz; \
+          c.jx = sr_.i32x; c.jy = sr_.i32y; c.jz = sr_.i32z; c.exact_only = sr_.exact_only ? 1 : 0; } \
         c.a = c.dx * c.dx + c.dy * c.dy + c.dz * c.dz; \
         c.closest = __builtin_inff(); c.best = -1; c.bmat = 0; c.node = node_first; \
         (P).segments++; \
@@ -194,18 +197,9 @@ __global__ void __launch_bounds__(BLOCK, MORT2_MIN_WAVES) mega_bvh2_kernel(const
                 PROF2(P_T, __popcll(__ballot(c.state == P_T)));
                 if (c.state == P_T) {
                     const DBvhNode nd = nodes[c.node];
-                    const bool nx = c.ix < 0, ny = c.iy < 0, nz = c.iz < 0;
-                    const float x0 = nx ? nd.xmax : nd.xmin, x1 = nx ? nd.xmin : nd.xmax;
-                    const float y0 = ny ? nd.ymax : nd.ymin, y1 = ny ? nd.ymin : nd.ymax;
-                    const float z0 = nz ? nd.zmax : nd.zmin, z1 = nz ? nd.zmin : nd.zmax;
-                    float t_min = 0.001f, t_max = c.closest;
-                    t_min = __builtin_fmaxf(t_min, (float)((double)(x0 - c.ox) * c.ix));
-                    t_max = __builtin_fminf(t_max, (float)((double)(x1 - c.ox) * c.ix));
-                    t_min = __builtin_fmaxf(t_min, (float)((double)(y0 - c.oy) * c.iy));
-                    t_max = __builtin_fminf(t_max, (float)((double)(y1 - c.oy) * c.iy));
-                    t_min = __builtin_fmaxf(t_min, (float)((double)(z0 - c.oz) * c.iz));
-                    t_max = __builtin_fminf(t_max, (float)((double)(z1 - c.oz) * c.iz));
-                    const bool miss = (t_max <= t_min);
+                    SlabRay sr; sr.ox = c.ox; sr.oy = c.oy; sr.oz = c.oz; sr.ix = c.ix; sr.iy = c.iy; sr.iz = c.iz;
+                    sr.i32x = c.jx; sr.i32y = c.jy; sr.i32z = c.jz; sr.exact_only = c.exact_only != 0;
+                    const bool miss = !slab_hit(nd, sr, c.closest);
                     const int skip = (int)(nd.skip & 0x7fffffffu);
                     if (miss) {
                         c.node = skip;

@@ -328,6 +328,7 @@ seed_kernel(const SeedArgs a) {
 
 #include "mega_bvh.h"
 #include "mega_bvh2.h"
+#include "wave_bvh.h"
 
 /* ====================================================================== host */
 
@@ -362,6 +363,11 @@ struct mort_ctx {
     int num_cus = 256;
     float4 *d_stack_ovf = nullptr; /* mega_bvh2: HBM overflow of the LDS bounce stacks */
     size_t stack_ovf_paths = 0;
+    /* wavefront mode work buffers */
+    void *d_wf = nullptr;
+    size_t wf_bytes = 0;
+    unsigned *h_live = nullptr; /* pinned */
+    int wf_fronts = 0;          /* fronts of the last wavefront render (reported) */
 };
 
 static int hip_fail(mort_ctx *c, hipError_t e, const char *what) {
@@ -460,7 +466,8 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->d_scene); hipFree(c->d_states); hipFree(c->d_seqmats);
-    hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_stack_ovf);
+    hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_stack_ovf); hipFree(c->d_wf);
+    if (c->h_live) hipHostFree(c->h_live);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -534,6 +541,7 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     comp.run();
     if (comp.out.status != MORT_OK) return comp.out.status;
     mortc::Compiled &o = comp.out;
+    if (o.inverted_box) return MORT_ERR_UNSUPPORTED; /* slab_hit orders planes with min/max: needs min <= max boxes */
 
     std::vector<unsigned char> blob;
     const size_t o_items = place(blob, o.items), o_sub = place(blob, o.subitems), o_nodes = place(blob, o.nodes);
@@ -671,11 +679,70 @@ static int check_light(const mort_ctx *c, int type, int idx) {
     return MORT_OK; /* any other tag samples nothing: pdf 0, direction (1,0,0) (objects.cuh:961,978) */
 }
 
+/* ---- wavefront mode: one wf_trav + one wf_shade launch per front until no pixel is live ---- */
+static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera *cam, hipStream_t s) {
+    const size_t N = (size_t)a.width * (size_t)a.local_rows;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t o_rays = 0, o_hits = o_rays + al(N * sizeof(WfRay)), o_pix = o_hits + al(N * sizeof(WfHit));
+    const size_t o_stack = o_pix + al(N * sizeof(WfPix)), o_q = o_stack + al(N * (size_t)cam->bounce_limit * sizeof(float4));
+    const size_t o_cnt = o_q + 5 * al(N * sizeof(unsigned)), total = o_cnt + al(sizeof(WfCounters));
+    if (c->wf_bytes < total) {
+        if (c->d_wf) { hipFree(c->d_wf); c->d_wf = nullptr; c->wf_bytes = 0; }
+        HIPCHK(c, hipMalloc(&c->d_wf, total));
+        c->wf_bytes = total;
+    }
+    if (!c->h_live) HIPCHK(c, hipHostMalloc((void **)&c->h_live, 64));
+    unsigned char *base = (unsigned char *)c->d_wf;
+    WfArgs w;
+    std::memset(&w, 0, sizeof w);
+    w.r = a;
+    w.hot_src = (const unsigned char *)c->d_scene; w.hot_bytes = c->hot_bytes;
+    w.off_nodes = c->off_nodes; w.off_spheres = c->off_spheres;
+    w.node_first = 0; w.node_count = c->sc.n_nodes;
+    w.n_paths = (int)N;
+    w.rays = (WfRay *)(base + o_rays); w.hits = (WfHit *)(base + o_hits); w.pix = (WfPix *)(base + o_pix);
+    w.stack = (float4 *)(base + o_stack);
+    for (int k = 0; k < 2; k++) w.q_trav[k] = (unsigned *)(base + o_q + (size_t)k * al(N * sizeof(unsigned)));
+    for (int k = 0; k < 3; k++) w.q_cls[k] = (unsigned *)(base + o_q + (size_t)(2 + k) * al(N * sizeof(unsigned)));
+    w.cnt = (WfCounters *)(base + o_cnt);
+
+    const int nb256 = (int)((N + 255) / 256);
+    hipLaunchKernelGGL(wf_init, dim3(nb256), dim3(256), 0, s, w);
+    HIPCHK(c, hipGetLastError());
+    auto trav = wf_trav<MORT_WF_BLOCK>;
+    const size_t trav_lds = ((c->hot_bytes + 15u) & ~15u) + (size_t)(MORT_WF_BLOCK / 64) * 3 * MORT_WF_STAGE * sizeof(unsigned);
+    HIPCHK(c, hipFuncSetAttribute((const void *)trav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trav_lds));
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav, MORT_WF_BLOCK, trav_lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    const int max_trav_grid = c->num_cus * per_cu;
+    const long long max_fronts = (long long)cam->sqrt_spp * cam->sqrt_spp * ((long long)cam->bounce_limit + 1) + 8;
+    size_t live = N;
+    long long front = 0;
+    const int chunk = 32;
+    while (live > 0 && front < max_fronts) {
+        int tg = (int)((live + MORT_WF_BLOCK - 1) / MORT_WF_BLOCK);
+        if (tg > max_trav_grid) tg = max_trav_grid;
+        if (tg < 1) tg = 1;
+        const int sg = (int)((live + 255) / 256) + 3;
+        for (int k = 0; k < chunk; k++, front++) {
+            w.parity = (int)(front & 1);
+            hipLaunchKernelGGL(trav, dim3(tg), dim3(MORT_WF_BLOCK), trav_lds, s, w);
+            hipLaunchKernelGGL(wf_shade, dim3(sg), dim3(256), 0, s, w);
+        }
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_live, &w.cnt->live, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        live = *c->h_live;
+    }
+    c->wf_fronts = (int)front;
+    if (live != 0) { c->last_error = "wavefront: front limit reached with live pixels"; return MORT_ERR_HIP; }
+    return MORT_OK;
+}
+
 extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum,
                                       void *stream, mort_stats *stats) {
     if (!c || !cam || !d_rgba) return MORT_ERR_INVALID;
-    if (mode == MORT_MODE_WAVE) return MORT_ERR_UNSUPPORTED;
-    if (mode != MORT_MODE_MEGA) return MORT_ERR_INVALID;
+    if (mode != MORT_MODE_MEGA && mode != MORT_MODE_WAVE) return MORT_ERR_INVALID;
     if (!c->have_world) return MORT_ERR_NO_WORLD;
     const int W = cam->image_width, H = cam->image_height;
     if (W <= 0 || H <= 0 || cam->sqrt_spp < 0) return MORT_ERR_INVALID;
@@ -713,8 +780,17 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
                           !(force && force[0] == '1');
     const bool use_v1 = use_fast && !(variant && variant[0] == '2'); /* MORT_FAST_VARIANT=2: two-paths-per-lane kernel */
     int lds_bytes_used = 0;
+    if (mode == MORT_MODE_WAVE) {
+        /* the wavefront pipeline covers: one BVH of spheres as the world, no light object */
+        if (!(c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1))
+            return MORT_ERR_UNSUPPORTED;
+    }
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
-    if (blocks > 0 && use_fast && !use_v1) {
+    if (blocks > 0 && mode == MORT_MODE_WAVE) {
+        int st_w = render_wavefront(c, a, cam, s);
+        if (st_w != MORT_OK) return st_w;
+        lds_bytes_used = (int)c->hot_bytes;
+    } else if (blocks > 0 && use_fast && !use_v1) {
         const int BLOCK = MORT2_BLOCK;
         Fast2Args fa;
         std::memset(&fa, 0, sizeof fa);
@@ -780,7 +856,15 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         unsigned long long cnt[32] = {0};
         HIPCHK(c, hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
 #ifdef MORT_PROFILE_STATES
-        if (use_fast && !use_v1) {
+        if (mode == MORT_MODE_WAVE) {
+            const char *nm[3] = {"T", "L", "F"};
+            const double tot = (double)(cnt[12] + cnt[13] + cnt[14] + cnt[15]);
+            for (int k = 0; k < 3; k++)
+                std::fprintf(stderr, "[wf_trav %s] %10llu wave-steps  util %5.1f%%  cycles %5.1f%% (%.0f/step)\n", nm[k], cnt[4 + k],
+                             cnt[4 + k] ? 100.0 * (double)cnt[8 + k] / (64.0 * (double)cnt[4 + k]) : 0.0, 100.0 * (double)cnt[12 + k] / tot,
+                             cnt[4 + k] ? (double)cnt[12 + k] / (double)cnt[4 + k] : 0.0);
+            std::fprintf(stderr, "[wf_trav sched] cycles %5.1f%%   fronts %d\n", 100.0 * (double)cnt[15] / tot, c->wf_fronts);
+        } else if (use_fast && !use_v1) {
             const char *nm[6] = {"sched", "FIN", "SPEC", "LAMB", "L", "T"};
             double tot = 0;
             for (int k = 0; k < 6; k++) tot += (double)cnt[16 + k];
@@ -797,10 +881,11 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         stats->pixels = (uint64_t)W * (uint64_t)a.local_rows;
         stats->eff_samples = stats->pixels * (uint64_t)(cam->sqrt_spp * cam->sqrt_spp);
         stats->algorithmic_hbm_bytes = stats->pixels * (uint64_t)(100 + (d_accum ? 12 : 0));
-        stats->scene_in_lds = use_fast ? 1 : 0;
+        stats->scene_in_lds = (use_fast || mode == MORT_MODE_WAVE) ? 1 : 0;
+        if (mode == MORT_MODE_WAVE) stats->algorithmic_hbm_bytes += 236ull * stats->segments; /* wave_bvh.h: per-segment record traffic */
         stats->local_rows = a.local_rows;
         hipFuncAttributes fattr;
-        const void *kf = !use_fast ? (const void *)mega_kernel
+        const void *kf = mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
                          : (use_v1 ? (const void *)mega_bvh_kernel<256, MORT_TH_S, MORT_TH_L, MORT_T_KEEP> : (const void *)mega_bvh2_kernel<MORT2_BLOCK, MORT2_TH_T>);
         if (hipFuncGetAttributes(&fattr, kf) == hipSuccess) {
             stats->kernel_vgprs = fattr.numRegs;

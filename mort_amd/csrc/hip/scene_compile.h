@@ -38,6 +38,7 @@ struct Compiled {
     std::vector<int> list_types, list_idxs;
     int list_first[MORT_NUM_HITTABLE_LIST], list_count[MORT_NUM_HITTABLE_LIST];
     int status = MORT_OK;
+    bool inverted_box = false; /* some BVH node has min > max on an axis */
 };
 
 static inline DSphere to_dsphere(const mort_sphere &s) {
@@ -181,6 +182,7 @@ struct Compiler {
         std::memset(&nd, 0, sizeof nd);
         const mort_aabb &bb = b.bounding_boxes[n];
         nd.xmin = bb.x.imin; nd.xmax = bb.x.imax; nd.ymin = bb.y.imin; nd.ymax = bb.y.imax; nd.zmin = bb.z.imin; nd.zmax = bb.z.imax;
+        if (nd.xmin > nd.xmax || nd.ymin > nd.ymax || nd.zmin > nd.zmax) out.inverted_box = true;
         out.nodes.push_back(nd);
         bool leaf = !b.is_internal_node[n];
         uint32_t prims = 0;

@@ -1,0 +1,486 @@
+/*
+ * wave_bvh.h -- MORT_MODE_WAVE: wavefront (queued) form of the render path for
+ * BVH scenes (one BVH of spheres, no light object).
+ *
+ * One path per pixel, all pixels of the rank in flight.  Each pixel's samples
+ * stay chained through its own XORWOW state (the reference's streams are
+ * pixel-serial, rng.cuh:17-23), so a "wave front" is one path segment of every
+ * live pixel.  Per front, two launches:
+ *
+ *   wf_trav   world::hit for every queued path.  Persistent workgroups, scene
+ *             hot blob in LDS; each lane pulls a path id from the front's
+ *             queue (one atomicAdd per wave, lanes ranked with mbcnt), walks
+ *             the threaded BVH with the T/L state machine of mega_bvh.h and,
+ *             when its ray is done, writes the 8-byte hit record, appends the
+ *             id to the queue of its shade class (ballot-compacted, one
+ *             atomicAdd per class per wave) and pulls the next id, so box
+ *             steps always run with nearly all lanes busy.
+ *   wf_shade  one workgroup = 256 ids of ONE class: diffuse (lambertian /
+ *             isotropic), specular (metal / dielectric / emissive) or finish
+ *             (miss: unwind the bounce stack, accumulate, next sample's camera
+ *             ray, or write the finished pixel).  No material divergence
+ *             inside a wave.  Surviving paths are appended to the next
+ *             front's queue.
+ *
+ * Path state lives in HBM as 16-byte-aligned records addressed by path id:
+ * ray 32 B, hit 8 B, pixel 48 B (XORWOW words, colour sum, packed counters),
+ * bounce stack [depth][path] 16 B.  Algorithmic traffic per segment:
+ * trav 32 r + 8 w + 8 queue; shade 32+8+48 r, 32+48+16 w, 4 queue = 236 B.
+ * Counters are double-buffered by front parity and zeroed by the kernel that
+ * runs between their last reader and next writer, so a front needs no memset.
+ */
+#ifndef MORT_WAVE_BVH_H
+#define MORT_WAVE_BVH_H
+
+#include "dev_trace.h"
+
+struct __attribute__((aligned(16))) WfRay { float ox, oy, oz, tm; float dx, dy, dz, time0; };
+struct __attribute__((aligned(8))) WfHit { float t; int best; };
+struct __attribute__((aligned(16))) WfPix {
+    uint32_t d, v0, v1, v2;
+    uint32_t v3, v4; float cr, cg;
+    float cb; uint32_t packed; /* s_i | s_j << 12 | iter << 24 */ uint32_t segments, draws;
+};
+
+enum { WC_LAMB = 0, WC_SPEC = 1, WC_FIN = 2 };
+
+/* counters, uint32 each.  [parity] sets for the class queues. */
+struct WfCounters {
+    unsigned trav_count[2];   /* ids in Q_trav[parity] */
+    unsigned trav_fetch;      /* work cursor of the running wf_trav */
+    unsigned cls_count[2][3]; /* ids in the class queues of front parity */
+    unsigned live;            /* pixels not finished yet */
+    unsigned pad[4];
+};
+
+struct WfArgs {
+    RenderArgs r;
+    const unsigned char *hot_src; uint32_t hot_bytes;
+    uint32_t off_nodes, off_spheres;
+    int node_first, node_count;
+    int n_paths;
+    WfRay *rays; WfHit *hits; WfPix *pix;
+    float4 *stack;            /* [bounce_limit][n_paths] */
+    unsigned *q_trav[2];      /* [n_paths] each */
+    unsigned *q_cls[3];       /* [n_paths] each */
+    WfCounters *cnt;
+    int parity;               /* front & 1 */
+};
+
+DEV Rng wf_rng_load(const WfPix &p) { Rng r; r.d = p.d; r.v0 = p.v0; r.v1 = p.v1; r.v2 = p.v2; r.v3 = p.v3; r.v4 = p.v4; r.draws = p.draws; return r; }
+DEV void wf_rng_store(WfPix &p, const Rng &r) { p.d = r.d; p.v0 = r.v0; p.v1 = r.v1; p.v2 = r.v2; p.v3 = r.v3; p.v4 = r.v4; p.draws = r.draws; }
+
+/* wave-compacted append of `id` for the lanes where `pred` holds; all lanes of the wave must call it */
+DEV void wf_push(unsigned *queue, unsigned *count, bool pred, unsigned id) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return;
+    const int n = __popcll(m);
+    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(count, (unsigned)n);
+    base = __shfl(base, leader);
+    if (pred) queue[base + (unsigned)rank] = id;
+}
+
+/* ---- front 0: load streams, first camera ray of every pixel ---- */
+extern "C" __global__ void __launch_bounds__(256) wf_init(const WfArgs w) {
+    const RenderArgs &a = w.r;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id == 0) {
+        w.cnt->trav_count[0] = (unsigned)w.n_paths; w.cnt->trav_count[1] = 0; w.cnt->trav_fetch = 0;
+        for (int p = 0; p < 2; p++) for (int k = 0; k < 3; k++) w.cnt->cls_count[p][k] = 0;
+        w.cnt->live = (unsigned)w.n_paths;
+    }
+    if (id >= w.n_paths) return;
+    const int ly = id / a.width, x = id - ly * a.width;
+    const int y = global_row(ly, a.rank, a.nranks, a.rows_per_block);
+    const mort_rng_state st = a.states[id];
+    Rng rng; rng.d = st.d; rng.v0 = st.v[0]; rng.v1 = st.v[1]; rng.v2 = st.v[2]; rng.v3 = st.v[3]; rng.v4 = st.v[4]; rng.draws = 0;
+    const Ray ray = get_ray(a, x, y, rng, 0, 0);
+    WfRay rr; rr.ox = ray.o.x; rr.oy = ray.o.y; rr.oz = ray.o.z; rr.tm = ray.tm; rr.dx = ray.d.x; rr.dy = ray.d.y; rr.dz = ray.d.z; rr.time0 = ray.tm;
+    w.rays[id] = rr;
+    WfPix p; wf_rng_store(p, rng); p.cr = p.cg = p.cb = 0; p.packed = 0; p.segments = 1; /* the segment this ray is about to trace */
+    w.pix[id] = p;
+    w.q_trav[0][id] = (unsigned)id;
+}
+
+/* ---- traversal of one front ---- */
+enum { W_T = 0, W_L = 1, W_F = 2, W_DONE = 3 };
+
+#ifndef MORT_WF_TH_F
+#define MORT_WF_TH_F 16
+#endif
+#ifndef MORT_WF_TH_L
+#define MORT_WF_TH_L 24
+#endif
+#ifndef MORT_WF_T_KEEP
+#define MORT_WF_T_KEEP 32
+#endif
+#ifndef MORT_WF_BLOCK
+#define MORT_WF_BLOCK 1024
+#endif
+
+#ifndef MORT_WF_STAGE
+#define MORT_WF_STAGE 192   /* ids per class staged in LDS per wave before a flush */
+#endif
+#ifndef MORT_WF_PULL
+#define MORT_WF_PULL 256    /* queue entries a wave reserves per global atomic */
+#endif
+
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    {
+        const uint4 *src = (const uint4 *)w.hot_src;
+        uint4 *dst = (uint4 *)lds;
+        const uint32_t n16 = w.hot_bytes >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
+    }
+    const int par = w.parity;
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.cnt->trav_count[par ^ 1] = 0; /* next front's queue: its last reader was wf_trav of the previous front */
+    __syncthreads();
+    const DBvhNode *nodes = (const DBvhNode *)(lds + w.off_nodes);
+    const DSphere *spheres = (const DSphere *)(lds + w.off_spheres);
+    /* per-wave staging of the class queues: a wave appends ids to its own LDS slices (no atomics: the
+     * wave runs in lockstep, cursors are wave-uniform) and flushes a slice with ONE global atomicAdd */
+    unsigned *stage = (unsigned *)(lds + ((w.hot_bytes + 15u) & ~15u)) + (threadIdx.x >> 6) * (3 * MORT_WF_STAGE);
+    int staged[3] = {0, 0, 0};
+    const int lane = threadIdx.x & 63;
+    const int node_first = w.node_first, node_end = w.node_first + w.node_count;
+    const unsigned n_items = w.cnt->trav_count[par];
+    const unsigned *queue = w.q_trav[par];
+    unsigned pull_base = 0, pull_left = 0; /* wave-uniform: reserved range of the front's queue */
+    bool exhausted = false;
+
+    int state = W_F;
+    bool have = false;
+    unsigned id = 0;
+    float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, tm = 0;
+    SlabRay sr = slab_ray(0, 0, 0, 0, 0, 1);
+    float ra = 1, closest = 0;
+    int best = -1, node = 0;
+    uint32_t bmat = 0, leaf = 0;
+
+#ifdef MORT_PROFILE_STATES
+    unsigned long long pr_steps[3] = {0, 0, 0}, pr_lanes[3] = {0, 0, 0}, pr_cyc[4] = {0, 0, 0, 0};
+    unsigned long long pt0 = __builtin_readcyclecounter(), pt1;
+#define WPROF(i, lanes) do { pr_steps[i] += 1; pr_lanes[i] += (unsigned long long)(lanes); } while (0)
+#define WPROFC(i) do { pt1 = __builtin_readcyclecounter(); pr_cyc[i] += pt1 - pt0; pt0 = pt1; } while (0)
+#else
+#define WPROF(i, lanes) do { } while (0)
+#define WPROFC(i) do { } while (0)
+#endif
+
+#define WF_FLUSH(k) do { \
+        if (staged[k] > 0) { \
+            unsigned base_ = 0; \
+            if (lane == 0) base_ = atomicAdd(&w.cnt->cls_count[par][k], (unsigned)staged[k]); \
+            base_ = __shfl(base_, 0); \
+            for (int i_ = lane; i_ < staged[k]; i_ += 64) w.q_cls[k][base_ + (unsigned)i_] = stage[(k) * MORT_WF_STAGE + i_]; \
+            staged[k] = 0; \
+        } } while (0)
+
+    for (;;) {
+        const int nT = __popcll(__ballot(state == W_T));
+        const int nL = __popcll(__ballot(state == W_L));
+        const int nF = __popcll(__ballot(state == W_F));
+        if (nT + nL + nF == 0) break;
+        int pick;
+        if (nF >= MORT_WF_TH_F) pick = W_F;
+        else if (nL >= MORT_WF_TH_L) pick = W_L;
+        else if (nT > 0) pick = W_T;
+        else pick = (nL >= nF) ? W_L : W_F;
+        WPROFC(3);
+
+        if (pick == W_T) {
+            int keep;
+            do {
+                WPROF(0, __popcll(__ballot(state == W_T)));
+                if (state == W_T) { /* aabb::hit + one move of the threaded walk (aabb.cuh:37-59, objects.cuh:664-723) */
+                    const DBvhNode nd = nodes[node];
+                    const bool miss = !slab_hit(nd, sr, closest);
+                    const int skip = (int)(nd.skip & 0x7fffffffu);
+                    if (miss) node = skip;
+                    else if (nd.skip >> 31) { leaf = nd.prims; node = skip; state = W_L; }
+                    else node = node + 1;
+                    if (state == W_T && node >= node_end) state = W_F;
+                }
+                keep = __popcll(__ballot(state == W_T));
+            } while (keep >= MORT_WF_T_KEEP);
+            WPROFC(0);
+        } else if (pick == W_L) {
+            WPROF(1, nL);
+            if (state == W_L) { /* sphere::hit on the leaf's spheres (objects.cuh:60-77,690-692) */
+                const uint32_t pa = leaf & 0x7fffu, pb = (leaf >> 16) & 0x7fffu;
+                Ray r; r.o = mk(ox, oy, oz); r.d = mk(dx, dy, dz); r.tm = tm;
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t p = k ? pb : pa;
+                    if (k == 1 && pb == pa) break;
+                    const DSphere sp = spheres[p];
+                    float t;
+                    if (sphere_hit_t(sp, r, ra, 0.001f, closest, t)) { closest = t; best = (int)p; bmat = sp.mat; }
+                }
+                state = (node >= node_end) ? W_F : W_T;
+            }
+            WPROFC(1);
+        } else {
+            WPROF(2, nF);
+            /* ---- retire finished rays (wave-uniform control flow: every lane runs this block) ---- */
+            const bool inF = (state == W_F);
+            int cls = -1;
+            if (inF && have) {
+                WfHit h; h.t = closest; h.best = best;
+                w.hits[id] = h;
+                if (best < 0) cls = WC_FIN;
+                else { const int mt = DREF_TYPE(bmat); cls = (mt == MORT_MAT_LAMBERTIAN || mt == MORT_MAT_ISOTROPIC) ? WC_LAMB : WC_SPEC; }
+                have = false;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const unsigned long long m = __ballot(cls == k);
+                const int n = __popcll(m);
+                if (n > 0) {
+                    if (staged[k] + n > MORT_WF_STAGE) WF_FLUSH(k);
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    if (cls == k) stage[k * MORT_WF_STAGE + staged[k] + rank] = id;
+                    staged[k] += n;
+                }
+            }
+            /* ---- pull the next paths from the wave's reserved range ---- */
+            const unsigned long long need = __ballot(inF);
+            int want = __popcll(need);
+            if (want > 0 && pull_left == 0 && !exhausted) {
+                unsigned b = 0;
+                if (lane == 0) b = atomicAdd(&w.cnt->trav_fetch, (unsigned)MORT_WF_PULL);
+                b = __shfl(b, 0);
+                if (b >= n_items) { exhausted = true; }
+                else { pull_base = b; pull_left = (n_items - b < (unsigned)MORT_WF_PULL) ? (n_items - b) : (unsigned)MORT_WF_PULL; }
+            }
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+            const unsigned serve = ((unsigned)want < pull_left) ? (unsigned)want : pull_left;
+            if (inF) {
+                if ((unsigned)rank < serve) {
+                    id = queue[pull_base + (unsigned)rank];
+                    const WfRay rr = w.rays[id];
+                    ox = rr.ox; oy = rr.oy; oz = rr.oz; tm = rr.tm; dx = rr.dx; dy = rr.dy; dz = rr.dz;
+                    sr = slab_ray(ox, oy, oz, dx, dy, dz);
+                    ra = dx * dx + dy * dy + dz * dz;
+                    closest = __builtin_inff(); best = -1; bmat = 0; node = node_first;
+                    have = true;
+                    state = (node_first < node_end) ? W_T : W_F;
+                } else if (exhausted || (pull_left == 0 && serve == 0 && exhausted)) {
+                    state = W_DONE;
+                }
+                /* else: stays in W_F, served from the next reservation */
+            }
+            pull_base += serve; pull_left -= serve;
+            WPROFC(2);
+        }
+    }
+    WF_FLUSH(0); WF_FLUSH(1); WF_FLUSH(2);
+#ifdef MORT_PROFILE_STATES
+    if (lane == 0) {
+        for (int k = 0; k < 3; k++) { atomicAdd(&w.r.counters[4 + k], pr_steps[k]); atomicAdd(&w.r.counters[8 + k], pr_lanes[k]); }
+        for (int k = 0; k < 4; k++) atomicAdd(&w.r.counters[12 + k], pr_cyc[k]);
+    }
+#endif
+#undef WF_FLUSH
+}
+
+/* ---- shading of one front ---- */
+DEV bool wf_texture(const DScene &sc, const DLambert &m, V3 outward, V3 p, V3 &color) {
+    color = mk(m.r, m.g, m.b);
+    if (m.tex == 0) return true;
+    float u = 0, v = 0;
+    /* only image textures / the error pattern read (u, v) */
+    uint32_t tex = m.tex;
+    for (int guard = 0; guard < 8; guard++) {
+        const int tt = DREF_TYPE(tex);
+        if (tt == MORT_TEXTURE_CHECKER) {
+            const DChecker c = sc.checker[DREF_IDX(tex)];
+            const int xi = mort_f2i(mort_floorf(c.inv_scale * p.x));
+            const int yi = mort_f2i(mort_floorf(c.inv_scale * p.y));
+            const int zi = mort_f2i(mort_floorf(c.inv_scale * p.z));
+            tex = ((xi + yi + zi) % 2 == 0) ? c.even : c.odd;
+            continue;
+        }
+        if (tt != MORT_TEXTURE_SOLID && tt != MORT_TEXTURE_NOISE) sphere_uv(outward, u, v);
+        break;
+    }
+    color = texture_value(sc, tex, u, v, p);
+    return true;
+}
+
+extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
+    const RenderArgs &a = w.r;
+    const DScene &sc = a.sc;
+    const int par = w.parity;
+    const unsigned n0 = w.cnt->cls_count[par][0], n1 = w.cnt->cls_count[par][1], n2 = w.cnt->cls_count[par][2];
+    const unsigned b0 = (n0 + 255u) >> 8, b1 = (n1 + 255u) >> 8, b2 = (n2 + 255u) >> 8;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        /* the other parity's class counters were last read by the previous wf_shade; wf_trav of this front is done */
+        w.cnt->cls_count[par ^ 1][0] = 0; w.cnt->cls_count[par ^ 1][1] = 0; w.cnt->cls_count[par ^ 1][2] = 0;
+        w.cnt->trav_fetch = 0;
+    }
+    unsigned b = blockIdx.x;
+    int cls;
+    unsigned n;
+    if (b < b0) { cls = WC_LAMB; n = n0; }
+    else if (b < b0 + b1) { cls = WC_SPEC; n = n1; b -= b0; }
+    else if (b < b0 + b1 + b2) { cls = WC_FIN; n = n2; b -= b0 + b1; }
+    else return;
+    const unsigned i = b * 256u + threadIdx.x;
+    const bool valid = i < n;
+    unsigned id = 0;
+    bool cont = false; /* path continues into the next front */
+    if (valid) {
+        id = w.q_cls[cls][i];
+        const WfRay rr = w.rays[id];
+        const WfHit h = w.hits[id];
+        WfPix P = w.pix[id];
+        Rng rng = wf_rng_load(P);
+        int s_i = (int)(P.packed & 0xfffu), s_j = (int)((P.packed >> 12) & 0xfffu), iter = (int)(P.packed >> 24);
+        Ray ray; ray.o = mk(rr.ox, rr.oy, rr.oz); ray.d = mk(rr.dx, rr.dy, rr.dz); ray.tm = rr.tm;
+        const float time0 = rr.time0;
+        V3 final_value = a.background; /* WC_FIN from wf_trav: a miss (camera.cuh:154-158) */
+        bool terminated = (cls == WC_FIN);
+        if (!terminated) {
+            const DSphere sp = sc.spheres[h.best];
+            const V3 p = ray_at(ray, h.t);
+            const V3 outward = vdiv(vsub(p, sphere_center(sp, ray.tm)), sp.radius);
+            const bool front_face = vdot(ray.d, outward) < 0;
+            const V3 normal = front_face ? outward : vneg(outward);
+            const int mtype = DREF_TYPE(sp.mat), midx = DREF_IDX(sp.mat);
+            float4 e;
+            V3 ndir = mk(0, 0, 1);
+            if (cls == WC_LAMB) { /* materials.cuh:38-55,182-198; pdf.cuh:29-54 */
+                const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
+                const DLambert m = lamb ? sc.lambert[midx] : sc.isotropic[midx];
+                V3 attenuation;
+                wf_texture(sc, m, outward, p, attenuation);
+                float mat_pdf, scattering_pdf;
+                if (lamb) {
+                    const Onb uvw = onb_from_w(normal);
+                    ndir = onb_local(uvw, random_cosine_direction(rng));
+                    const V3 ud = vunit(ndir);
+                    const float cosine_theta = vdot(ud, uvw.w);
+                    mat_pdf = mort_fmaxf(0, (float)((double)cosine_theta / 3.1415926));
+                    const float cos_theta = vdot(normal, ud);
+                    scattering_pdf = (cos_theta < 0) ? 0.0f : (float)((double)cos_theta / 3.141592565);
+                } else {
+                    ndir = random_unit_vector(rng);
+                    mat_pdf = (float)(1 / (4 * 3.1415926));
+                    scattering_pdf = (float)(1 / (4 * 3.1415926));
+                }
+                e.x = scattering_pdf * attenuation.x; e.y = scattering_pdf * attenuation.y; e.z = scattering_pdf * attenuation.z;
+                e.w = 1 / mat_pdf;
+                ray.tm = time0; /* ray(rec.p, dir, r.time()) (camera.cuh:119) */
+            } else if (mtype == MORT_MAT_METAL) { /* materials.cuh:73-84 */
+                const DMetal m = sc.metal[midx];
+                const V3 reflected = reflect(ray.d, normal);
+                ndir = vadd(vunit(reflected), vscale(m.fuzz, random_unit_vector(rng)));
+                e.x = 1.0f * m.r; e.y = 1.0f * m.g; e.z = 1.0f * m.b; e.w = 1.0f;
+            } else if (mtype == MORT_MAT_DIELECTRIC) { /* materials.cuh:107-130 */
+                const DDielectric m = sc.dielectric[midx];
+                const float refraction_ratio = front_face ? m.inv_ior : m.ior;
+                const V3 unit_direction = vunit(ray.d);
+                const float cos_theta = (float)mort_fmin((double)vdot(vneg(unit_direction), normal), 1.0);
+                const float sin_theta = (float)mort_sqrt(1.0 - (double)(cos_theta * cos_theta));
+                const bool cant_refract = (double)(refraction_ratio * sin_theta) > 1.0;
+                if (cant_refract || reflectance(cos_theta, refraction_ratio) > random_float(rng))
+                    ndir = reflect(unit_direction, normal);
+                else
+                    ndir = refract(unit_direction, normal, refraction_ratio);
+                e.x = 1.0f; e.y = 1.0f; e.z = 1.0f; e.w = 1.0f;
+            } else { /* diffuse_light / unknown tag: no scatter (materials.cuh:151-163) */
+                V3 emission = mk(0, 0, 0);
+                if (mtype == MORT_MAT_DIFFUSE_LIGHT && front_face) wf_texture(sc, sc.dlight[midx], outward, p, emission);
+                final_value = emission;
+                terminated = true;
+            }
+            if (!terminated) {
+                w.stack[(size_t)iter * (size_t)w.n_paths + id] = e;
+                iter++;
+                ray.o = p; ray.d = ndir;
+                if (iter >= a.bounce_limit) { final_value = mk(0, 0, 0); terminated = true; } /* camera.cuh:161-163 */
+                else { P.segments++; cont = true; }
+            }
+        }
+        if (terminated) { /* unwind + accumulate (camera.cuh:165-173,190), then the next sample or the finished pixel */
+            while (iter > 0) {
+                iter--;
+                const float4 e = w.stack[(size_t)iter * (size_t)w.n_paths + id];
+                const V3 t = vmul(mk(e.x, e.y, e.z), final_value);
+                final_value = vadd(mk(0, 0, 0), vscale(e.w, t));
+            }
+            P.cr += final_value.x; P.cg += final_value.y; P.cb += final_value.z;
+            s_i++;
+            if (s_i >= a.sqrt_spp) { s_i = 0; s_j++; }
+            const int ly = (int)id / a.width, x = (int)id - ly * a.width;
+            if (s_j < a.sqrt_spp) {
+                const int y = global_row(ly, a.rank, a.nranks, a.rows_per_block);
+                ray = get_ray(a, x, y, rng, s_i, s_j);
+                P.segments++;
+                cont = true;
+            } else { /* camera.cuh:194-207 */
+                V3 col = vscale(a.pixel_samples_scale, mk(P.cr, P.cg, P.cb));
+                if (col.x != col.x) col.x = 0.0f;
+                if (col.y != col.y) col.y = 0.0f;
+                if (col.z != col.z) col.z = 0.0f;
+                if (a.accum) { a.accum[3 * id] = col.x; a.accum[3 * id + 1] = col.y; a.accum[3 * id + 2] = col.z; }
+                float g[3] = {mort_sqrtf(col.x), mort_sqrtf(col.y), mort_sqrtf(col.z)};
+                unsigned char bq[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float v = g[k];
+                    if (v < 0.0f) v = 0.0f;
+                    if (v > 0.999f) v = 0.999f;
+                    bq[k] = (unsigned char)mort_f2i(256 * v);
+                }
+                uchar4 out; out.x = bq[0]; out.y = bq[1]; out.z = bq[2]; out.w = 255;
+                a.rgba[id] = out;
+                if (a.seg_px) a.seg_px[id] = P.segments;
+                mort_rng_state st;
+                st.d = rng.d; st.v[0] = rng.v0; st.v[1] = rng.v1; st.v[2] = rng.v2; st.v[3] = rng.v3; st.v[4] = rng.v4;
+                st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
+                a.states[id] = st;
+                atomicAdd(&a.counters[0], (unsigned long long)P.segments);
+                atomicAdd(&a.counters[1], (unsigned long long)rng.draws);
+                cont = false;
+            }
+            if (cont) { iter = 0; }
+        }
+        if (cont) {
+            wf_rng_store(P, rng);
+            P.packed = (uint32_t)s_i | ((uint32_t)s_j << 12) | ((uint32_t)iter << 24);
+            w.pix[id] = P;
+            WfRay o; o.ox = ray.o.x; o.oy = ray.o.y; o.oz = ray.o.z; o.tm = ray.tm; o.dx = ray.d.x; o.dy = ray.d.y; o.dz = ray.d.z;
+            o.time0 = terminated ? ray.tm : time0;
+            w.rays[id] = o;
+        }
+    }
+    /* append the survivors to the next front's queue: one global atomicAdd per workgroup */
+    {
+        __shared__ unsigned s_cnt[4], s_fin[4], s_base;
+        const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const unsigned long long m = __ballot(cont);
+        const unsigned long long mf = __ballot(valid && !cont);
+        if (lane == 0) { s_cnt[wv] = (unsigned)__popcll(m); s_fin[wv] = (unsigned)__popcll(mf); }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+            const unsigned fin = s_fin[0] + s_fin[1] + s_fin[2] + s_fin[3];
+            s_base = tot ? atomicAdd(&w.cnt->trav_count[par ^ 1], tot) : 0u;
+            if (fin) atomicSub(&w.cnt->live, fin); /* only finished pixels change the live count */
+        }
+        __syncthreads();
+        unsigned off = s_base;
+        for (int k = 0; k < wv; k++) off += s_cnt[k];
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (cont) w.q_trav[par ^ 1][off + (unsigned)rank] = id;
+    }
+}
+
+#endif

@@ -9,6 +9,7 @@ cases = [(1, 200, 4, None), (10, 200, 1, None), (2, 160, 4, None), (5, 96, 16, N
          (7, 64, 16, None), (4, 160, 4, None), (3, 160, 4, None), (9, 64, 16, None)]
 if len(sys.argv) > 1:
     cases = [tuple(int(v) if v != 'None' else None for v in a.split(',')) for a in sys.argv[1:]]
+MODE = int(os.environ.get('MORT_PROBE_MODE', '0'))
 ctx = hip.Context(0)
 ok = True
 for sid, w, spp, depth in cases:
@@ -21,7 +22,7 @@ for sid, w, spp, depth in cases:
     st0 = ctx.rng_store(cam.image_width, cam.image_height, O.STATE_DTYPE)
     seeds = O.seed_states(69420, cam.image_width, cam.image_height)
     seed_ok = bool((st0['d'] == seeds['d']).all() and (st0['v'] == seeds['v']).all())
-    out = ctx.render(cam, want_accum=True, want_segments=True)
+    out = ctx.render(cam, mode=MODE, want_accum=True, want_segments=True)
     st1 = ctx.rng_store(cam.image_width, cam.image_height, O.STATE_DTYPE)
     rg = (out['rgba'] != ref['rgba']).any(axis=-1).sum()
     ac = (out['accum'].view(np.uint32) != ref['accum'].view(np.uint32)).any(axis=-1).sum()

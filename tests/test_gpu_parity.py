@@ -140,6 +140,32 @@ def test_partition_invariance(gpu_ctx, oracle, nranks, rpb):
     assert (rgba == ref["rgba"]).all() and (accum.view(np.uint32) == ref["accum"].view(np.uint32)).all()
 
 
+WAVE_CASES = [(1, 200, 4, None), (10, 160, 1, None), (1, 96, 9, 3), (1, 61, 5, 1), (1, 130, 16, 50)]
+
+
+@pytest.mark.parametrize("sid,width,spp,depth", WAVE_CASES)
+def test_wavefront_mode_matches_oracle(gpu_ctx, oracle, sid, width, spp, depth):
+    """MORT_MODE_WAVE (queued pipeline, wave_bvh.h) produces the same bits as the oracle and the megakernel."""
+    world, cam = host.build_scene(sid, width=width, spp=spp, depth=depth)
+    ref = oracle.render(world, cam, nthreads=8)
+    gpu_ctx.set_partition(0, 1, 8)
+    gpu_ctx.upload_world(world)
+    gpu_ctx.rng_seed(S.DEFAULT_SEED, cam.image_width, cam.image_height)
+    out = gpu_ctx.render(cam, mode=hip.MODE_WAVE, want_accum=True, want_segments=True)
+    out["states"] = gpu_ctx.rng_store(cam.image_width, cam.image_height, oracle.STATE_DTYPE)
+    assert_same(out, ref)
+
+
+def test_wavefront_mode_rejects_unsupported_scenes(gpu_ctx):
+    world, cam = host.build_scene(6, width=32, spp=1)  # lights + quads: megakernel only for now
+    gpu_ctx.set_partition(0, 1, 8)
+    gpu_ctx.upload_world(world)
+    gpu_ctx.rng_seed(1, cam.image_width, cam.image_height)
+    with pytest.raises(hip.MortHipError) as e:
+        gpu_ctx.render(cam, mode=hip.MODE_WAVE)
+    assert e.value.status == -6
+
+
 def test_full_geometry_low_spp(gpu_ctx, oracle):
     """The headline geometry (Scene 1, 1200x675) at 4 spp against the oracle, bit for bit."""
     world, cam = host.build_scene(1, spp=4)
@@ -185,8 +211,8 @@ def test_error_paths(oracle):
         ctx.rng_seed(1, cam.image_width, cam.image_height)
         ctx.render(cam)
         with pytest.raises(hip.MortHipError) as e:
-            ctx.render(cam, mode=hip.MODE_WAVE)
-        assert e.value.status == -6  # wavefront pipeline not built yet
+            ctx.render(cam, mode=7)
+        assert e.value.status == -1  # unknown mode
         _, deep = host.build_scene(1, width=32, spp=1, depth=S.MAX_BOUNCE_LIMIT + 1)
         with pytest.raises(hip.MortHipError) as e:
             ctx.render(deep)
