@@ -683,9 +683,15 @@ static int check_light(const mort_ctx *c, int type, int idx) {
 static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera *cam, hipStream_t s) {
     const size_t N = (size_t)a.width * (size_t)a.local_rows;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t o_rays = 0, o_hits = o_rays + al(N * sizeof(WfRay)), o_pix = o_hits + al(N * sizeof(WfHit));
-    const size_t o_stack = o_pix + al(N * sizeof(WfPix)), o_q = o_stack + al(N * (size_t)cam->bounce_limit * sizeof(float4));
-    const size_t o_cnt = o_q + 5 * al(N * sizeof(unsigned)), total = o_cnt + al(sizeof(WfCounters));
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += al(bytes); return o; };
+    const size_t o_ray0 = take(N * sizeof(WfRay)), o_ray1 = take(N * sizeof(WfRay));
+    const size_t o_id0 = take(N * sizeof(unsigned)), o_id1 = take(N * sizeof(unsigned));
+    const size_t o_hits = take(N * sizeof(WfHit)), o_pix = take(N * sizeof(WfPix));
+    const size_t o_stack = take(N * (size_t)cam->bounce_limit * sizeof(float4));
+    const size_t o_c0 = take(N * sizeof(unsigned)), o_c1 = take(N * sizeof(unsigned)), o_c2 = take(N * sizeof(unsigned));
+    const size_t o_cnt = take(sizeof(WfCounters));
+    const size_t total = off;
     if (c->wf_bytes < total) {
         if (c->d_wf) { hipFree(c->d_wf); c->d_wf = nullptr; c->wf_bytes = 0; }
         HIPCHK(c, hipMalloc(&c->d_wf, total));
@@ -700,17 +706,21 @@ static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera 
     w.off_nodes = c->off_nodes; w.off_spheres = c->off_spheres;
     w.node_first = 0; w.node_count = c->sc.n_nodes;
     w.n_paths = (int)N;
-    w.rays = (WfRay *)(base + o_rays); w.hits = (WfHit *)(base + o_hits); w.pix = (WfPix *)(base + o_pix);
+    w.q_ray[0] = (WfRay *)(base + o_ray0); w.q_ray[1] = (WfRay *)(base + o_ray1);
+    w.q_id[0] = (unsigned *)(base + o_id0); w.q_id[1] = (unsigned *)(base + o_id1);
+    w.hits = (WfHit *)(base + o_hits); w.pix = (WfPix *)(base + o_pix);
     w.stack = (float4 *)(base + o_stack);
-    for (int k = 0; k < 2; k++) w.q_trav[k] = (unsigned *)(base + o_q + (size_t)k * al(N * sizeof(unsigned)));
-    for (int k = 0; k < 3; k++) w.q_cls[k] = (unsigned *)(base + o_q + (size_t)(2 + k) * al(N * sizeof(unsigned)));
+    w.q_cls[0] = (unsigned *)(base + o_c0); w.q_cls[1] = (unsigned *)(base + o_c1); w.q_cls[2] = (unsigned *)(base + o_c2);
     w.cnt = (WfCounters *)(base + o_cnt);
 
     const int nb256 = (int)((N + 255) / 256);
     hipLaunchKernelGGL(wf_init, dim3(nb256), dim3(256), 0, s, w);
     HIPCHK(c, hipGetLastError());
     auto trav = wf_trav<MORT_WF_BLOCK>;
-    const size_t trav_lds = ((c->hot_bytes + 15u) & ~15u) + (size_t)(MORT_WF_BLOCK / 64) * 3 * MORT_WF_STAGE * sizeof(unsigned);
+    const size_t stage_bytes = (size_t)(MORT_WF_BLOCK / 64) * 3 * MORT_WF_STAGE * sizeof(unsigned);
+    const size_t ring_off = ((((c->hot_bytes + 15u) & ~15u) + stage_bytes) + 1023) & ~(size_t)1023;
+    const size_t trav_lds = ring_off + (size_t)(MORT_WF_BLOCK / 64) * 4096; /* hot blob | class staging | prefetch rings */
+    w.off_ring = (uint32_t)ring_off;
     HIPCHK(c, hipFuncSetAttribute((const void *)trav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trav_lds));
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav, MORT_WF_BLOCK, trav_lds) != hipSuccess || per_cu < 1) per_cu = 1;
@@ -720,7 +730,8 @@ static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera 
     long long front = 0;
     const int chunk = 32;
     while (live > 0 && front < max_fronts) {
-        int tg = (int)((live + MORT_WF_BLOCK - 1) / MORT_WF_BLOCK);
+        /* a wave's slice should hold at least two 64-record batches: fewer, fuller workgroups on small fronts */
+        int tg = (int)((live + (size_t)(MORT_WF_BLOCK / 64) * 128 - 1) / ((size_t)(MORT_WF_BLOCK / 64) * 128));
         if (tg > max_trav_grid) tg = max_trav_grid;
         if (tg < 1) tg = 1;
         const int sg = (int)((live + 255) / 256) + 3;
@@ -864,6 +875,8 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
                              cnt[4 + k] ? 100.0 * (double)cnt[8 + k] / (64.0 * (double)cnt[4 + k]) : 0.0, 100.0 * (double)cnt[12 + k] / tot,
                              cnt[4 + k] ? (double)cnt[12 + k] / (double)cnt[4 + k] : 0.0);
             std::fprintf(stderr, "[wf_trav sched] cycles %5.1f%%   fronts %d\n", 100.0 * (double)cnt[15] / tot, c->wf_fronts);
+            std::fprintf(stderr, "[wf_trav waves] %llu waves, mean lifetime %.1f us, in-loop cycles per wave %.0f\n", cnt[21],
+                         cnt[21] ? (double)cnt[20] / (double)cnt[21] * 0.01 : 0.0, cnt[21] ? tot / (double)cnt[21] : 0.0);
         } else if (use_fast && !use_v1) {
             const char *nm[6] = {"sched", "FIN", "SPEC", "LAMB", "L", "T"};
             double tot = 0;
@@ -882,7 +895,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         stats->eff_samples = stats->pixels * (uint64_t)(cam->sqrt_spp * cam->sqrt_spp);
         stats->algorithmic_hbm_bytes = stats->pixels * (uint64_t)(100 + (d_accum ? 12 : 0));
         stats->scene_in_lds = (use_fast || mode == MORT_MODE_WAVE) ? 1 : 0;
-        if (mode == MORT_MODE_WAVE) stats->algorithmic_hbm_bytes += 236ull * stats->segments; /* wave_bvh.h: per-segment record traffic */
+        if (mode == MORT_MODE_WAVE) stats->algorithmic_hbm_bytes += 240ull * stats->segments; /* wave_bvh.h: per-segment record traffic */
         stats->local_rows = a.local_rows;
         hipFuncAttributes fattr;
         const void *kf = mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel

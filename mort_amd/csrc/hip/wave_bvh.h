@@ -4,28 +4,32 @@
  *
  * One path per pixel, all pixels of the rank in flight.  Each pixel's samples
  * stay chained through its own XORWOW state (the reference's streams are
- * pixel-serial, rng.cuh:17-23), so a "wave front" is one path segment of every
- * live pixel.  Per front, two launches:
+ * pixel-serial, rng.cuh:17-23), so a "front" is one path segment of every
+ * live pixel.  A front is a COMPACT array of (path id, ray) records in HBM;
+ * per front, two launches:
  *
- *   wf_trav   world::hit for every queued path.  Persistent workgroups, scene
- *             hot blob in LDS; each lane pulls a path id from the front's
- *             queue (one atomicAdd per wave, lanes ranked with mbcnt), walks
- *             the threaded BVH with the T/L state machine of mega_bvh.h and,
- *             when its ray is done, writes the 8-byte hit record, appends the
- *             id to the queue of its shade class (ballot-compacted, one
- *             atomicAdd per class per wave) and pulls the next id, so box
- *             steps always run with nearly all lanes busy.
- *   wf_shade  one workgroup = 256 ids of ONE class: diffuse (lambertian /
- *             isotropic), specular (metal / dielectric / emissive) or finish
- *             (miss: unwind the bounce stack, accumulate, next sample's camera
- *             ray, or write the finished pixel).  No material divergence
- *             inside a wave.  Surviving paths are appended to the next
- *             front's queue.
+ *   wf_trav   world::hit for every record of the front.  Scene hot blob in
+ *             LDS.  Each wave owns a contiguous slice of the front and streams
+ *             it through two 64-record register buffers (coalesced 32-byte
+ *             loads, issued one batch ahead); a lane whose ray is done takes
+ *             the next record by cross-lane shuffle (rank among the waiting
+ *             lanes -> buffer slot), so the box-test loop runs with nearly all
+ *             lanes busy and no load sits on the refill path.  Retiring a ray
+ *             writes its 8-byte hit record at the ray's position and appends
+ *             that position to the queue of its shade class, staged per wave
+ *             in LDS and flushed with one global atomicAdd per ~190 entries.
+ *   wf_shade  one workgroup = 256 positions of ONE class: diffuse
+ *             (lambertian / isotropic), specular (metal / dielectric /
+ *             emissive) or finish (miss: unwind the bounce stack, accumulate,
+ *             next sample's camera ray, or write the finished pixel).  No
+ *             material divergence inside a wave.  Surviving paths are appended
+ *             to the next front (one atomicAdd per workgroup, coalesced
+ *             32-byte ray writes).
  *
- * Path state lives in HBM as 16-byte-aligned records addressed by path id:
- * ray 32 B, hit 8 B, pixel 48 B (XORWOW words, colour sum, packed counters),
- * bounce stack [depth][path] 16 B.  Algorithmic traffic per segment:
- * trav 32 r + 8 w + 8 queue; shade 32+8+48 r, 32+48+16 w, 4 queue = 236 B.
+ * HBM records: front ray 32 B + id 4 B (two parities), hit 8 B (by position),
+ * pixel 48 B (by id: XORWOW words, colour sum, packed counters), bounce stack
+ * [depth][id] 16 B.  Algorithmic traffic per segment: trav 32 r + 8 w + 4 q;
+ * shade 4 q + 4 + 32 + 8 + 48 r, 4 + 32 + 48 + 16 w = 240 B.
  * Counters are double-buffered by front parity and zeroed by the kernel that
  * runs between their last reader and next writer, so a front needs no memset.
  */
@@ -44,25 +48,26 @@ struct __attribute__((aligned(16))) WfPix {
 
 enum { WC_LAMB = 0, WC_SPEC = 1, WC_FIN = 2 };
 
-/* counters, uint32 each.  [parity] sets for the class queues. */
 struct WfCounters {
-    unsigned trav_count[2];   /* ids in Q_trav[parity] */
-    unsigned trav_fetch;      /* work cursor of the running wf_trav */
-    unsigned cls_count[2][3]; /* ids in the class queues of front parity */
+    unsigned front_count[2];  /* records in front[parity] */
+    unsigned cls_count[2][3]; /* positions in the class queues of front parity */
     unsigned live;            /* pixels not finished yet */
-    unsigned pad[4];
+    unsigned pad[7];
 };
 
 struct WfArgs {
     RenderArgs r;
     const unsigned char *hot_src; uint32_t hot_bytes;
     uint32_t off_nodes, off_spheres;
+    uint32_t off_ring;        /* LDS offset of the per-wave prefetch rings (wf_trav) */
     int node_first, node_count;
     int n_paths;
-    WfRay *rays; WfHit *hits; WfPix *pix;
+    unsigned *q_id[2];        /* front[parity]: path id of each record */
+    WfRay *q_ray[2];          /* front[parity]: its ray */
+    WfHit *hits;              /* by position in the current front */
+    WfPix *pix;               /* by path id */
     float4 *stack;            /* [bounce_limit][n_paths] */
-    unsigned *q_trav[2];      /* [n_paths] each */
-    unsigned *q_cls[3];       /* [n_paths] each */
+    unsigned *q_cls[3];       /* positions, per shade class */
     WfCounters *cnt;
     int parity;               /* front & 1 */
 };
@@ -70,25 +75,12 @@ struct WfArgs {
 DEV Rng wf_rng_load(const WfPix &p) { Rng r; r.d = p.d; r.v0 = p.v0; r.v1 = p.v1; r.v2 = p.v2; r.v3 = p.v3; r.v4 = p.v4; r.draws = p.draws; return r; }
 DEV void wf_rng_store(WfPix &p, const Rng &r) { p.d = r.d; p.v0 = r.v0; p.v1 = r.v1; p.v2 = r.v2; p.v3 = r.v3; p.v4 = r.v4; p.draws = r.draws; }
 
-/* wave-compacted append of `id` for the lanes where `pred` holds; all lanes of the wave must call it */
-DEV void wf_push(unsigned *queue, unsigned *count, bool pred, unsigned id) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return;
-    const int n = __popcll(m);
-    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-    const int leader = __ffsll((long long)m) - 1;
-    unsigned base = 0;
-    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(count, (unsigned)n);
-    base = __shfl(base, leader);
-    if (pred) queue[base + (unsigned)rank] = id;
-}
-
 /* ---- front 0: load streams, first camera ray of every pixel ---- */
 extern "C" __global__ void __launch_bounds__(256) wf_init(const WfArgs w) {
     const RenderArgs &a = w.r;
     const int id = blockIdx.x * blockDim.x + threadIdx.x;
     if (id == 0) {
-        w.cnt->trav_count[0] = (unsigned)w.n_paths; w.cnt->trav_count[1] = 0; w.cnt->trav_fetch = 0;
+        w.cnt->front_count[0] = (unsigned)w.n_paths; w.cnt->front_count[1] = 0;
         for (int p = 0; p < 2; p++) for (int k = 0; k < 3; k++) w.cnt->cls_count[p][k] = 0;
         w.cnt->live = (unsigned)w.n_paths;
     }
@@ -99,10 +91,10 @@ extern "C" __global__ void __launch_bounds__(256) wf_init(const WfArgs w) {
     Rng rng; rng.d = st.d; rng.v0 = st.v[0]; rng.v1 = st.v[1]; rng.v2 = st.v[2]; rng.v3 = st.v[3]; rng.v4 = st.v[4]; rng.draws = 0;
     const Ray ray = get_ray(a, x, y, rng, 0, 0);
     WfRay rr; rr.ox = ray.o.x; rr.oy = ray.o.y; rr.oz = ray.o.z; rr.tm = ray.tm; rr.dx = ray.d.x; rr.dy = ray.d.y; rr.dz = ray.d.z; rr.time0 = ray.tm;
-    w.rays[id] = rr;
+    w.q_ray[0][id] = rr;
+    w.q_id[0][id] = (unsigned)id;
     WfPix p; wf_rng_store(p, rng); p.cr = p.cg = p.cb = 0; p.packed = 0; p.segments = 1; /* the segment this ray is about to trace */
     w.pix[id] = p;
-    w.q_trav[0][id] = (unsigned)id;
 }
 
 /* ---- traversal of one front ---- */
@@ -118,19 +110,18 @@ enum { W_T = 0, W_L = 1, W_F = 2, W_DONE = 3 };
 #define MORT_WF_T_KEEP 32
 #endif
 #ifndef MORT_WF_BLOCK
-#define MORT_WF_BLOCK 1024
+#define MORT_WF_BLOCK 512
 #endif
-
 #ifndef MORT_WF_STAGE
-#define MORT_WF_STAGE 192   /* ids per class staged in LDS per wave before a flush */
-#endif
-#ifndef MORT_WF_PULL
-#define MORT_WF_PULL 256    /* queue entries a wave reserves per global atomic */
+#define MORT_WF_STAGE 128 /* positions per class staged in LDS per wave before a flush */
 #endif
 
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+#ifdef MORT_PROFILE_STATES
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     {
         const uint4 *src = (const uint4 *)w.hot_src;
         uint4 *dst = (uint4 *)lds;
@@ -138,29 +129,57 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
     }
     const int par = w.parity;
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.cnt->trav_count[par ^ 1] = 0; /* next front's queue: its last reader was wf_trav of the previous front */
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.cnt->front_count[par ^ 1] = 0; /* next front: its last reader was the previous wf_trav */
     __syncthreads();
     const DBvhNode *nodes = (const DBvhNode *)(lds + w.off_nodes);
     const DSphere *spheres = (const DSphere *)(lds + w.off_spheres);
-    /* per-wave staging of the class queues: a wave appends ids to its own LDS slices (no atomics: the
-     * wave runs in lockstep, cursors are wave-uniform) and flushes a slice with ONE global atomicAdd */
     unsigned *stage = (unsigned *)(lds + ((w.hot_bytes + 15u) & ~15u)) + (threadIdx.x >> 6) * (3 * MORT_WF_STAGE);
     int staged[3] = {0, 0, 0};
     const int lane = threadIdx.x & 63;
     const int node_first = w.node_first, node_end = w.node_first + w.node_count;
-    const unsigned n_items = w.cnt->trav_count[par];
-    const unsigned *queue = w.q_trav[par];
-    unsigned pull_base = 0, pull_left = 0; /* wave-uniform: reserved range of the front's queue */
-    bool exhausted = false;
+    const unsigned n_items = w.cnt->front_count[par];
+    const WfRay *front = w.q_ray[par];
+
+    /* this wave's share of the front: 64-record batches wave_id, wave_id + n_waves, ... (strided, so every
+     * wave samples the whole image: fronts are in pixel order and cost varies by region) */
+    const unsigned n_waves = gridDim.x * (BLOCK / 64), wave_id = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    unsigned next_batch = wave_id;
+    /* Prefetch ring: two batches of 64 records per wave in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no
+     * VGPR destination, so nothing forces an early wait).  plane 0 = {ox,oy,oz,tm}, plane 1 = {dx,dy,dz,time0}. */
+    float4 *ring = (float4 *)(lds + w.off_ring) + (threadIdx.x >> 6) * 256; /* [buf][plane][64] */
+    unsigned A_base = 0, B_base = 0;
+    int A_cnt = 0, A_head = 0, B_cnt = 0, cur = 0;
+#define WF_DMA(BUFIDX, BASE, CNT) do { \
+        BASE = next_batch * 64u; \
+        CNT = (BASE < n_items) ? (int)((n_items - BASE < 64u) ? (n_items - BASE) : 64u) : 0; \
+        next_batch += n_waves; \
+        if (CNT > 0) { \
+            const unsigned i_ = BASE + (unsigned)((lane < CNT) ? lane : 0); \
+            const float4 *g_ = (const float4 *)(front + i_); \
+            __builtin_amdgcn_global_load_lds((const void *)g_, (__attribute__((address_space(3))) void *)(ring + (BUFIDX) * 128), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((const void *)(g_ + 1), (__attribute__((address_space(3))) void *)(ring + (BUFIDX) * 128 + 64), 16, 0, 0); \
+        } } while (0)
+    WF_DMA(0, A_base, A_cnt);
+    WF_DMA(1, B_base, B_cnt);
+    bool ring_fresh = true; /* the first read of a batch needs its DMA to have landed */
 
     int state = W_F;
     bool have = false;
-    unsigned id = 0;
+    unsigned pos = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, tm = 0;
     SlabRay sr = slab_ray(0, 0, 0, 0, 0, 1);
     float ra = 1, closest = 0;
     int best = -1, node = 0;
     uint32_t bmat = 0, leaf = 0;
+
+#define WF_FLUSH(k) do { \
+        if (staged[k] > 0) { \
+            unsigned base_ = 0; \
+            if (lane == 0) base_ = atomicAdd(&w.cnt->cls_count[par][k], (unsigned)staged[k]); \
+            base_ = __shfl(base_, 0); \
+            for (int i_ = lane; i_ < staged[k]; i_ += 64) w.q_cls[k][base_ + (unsigned)i_] = stage[(k) * MORT_WF_STAGE + i_]; \
+            staged[k] = 0; \
+        } } while (0)
 
 #ifdef MORT_PROFILE_STATES
     unsigned long long pr_steps[3] = {0, 0, 0}, pr_lanes[3] = {0, 0, 0}, pr_cyc[4] = {0, 0, 0, 0};
@@ -171,15 +190,6 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
 #define WPROF(i, lanes) do { } while (0)
 #define WPROFC(i) do { } while (0)
 #endif
-
-#define WF_FLUSH(k) do { \
-        if (staged[k] > 0) { \
-            unsigned base_ = 0; \
-            if (lane == 0) base_ = atomicAdd(&w.cnt->cls_count[par][k], (unsigned)staged[k]); \
-            base_ = __shfl(base_, 0); \
-            for (int i_ = lane; i_ < staged[k]; i_ += 64) w.q_cls[k][base_ + (unsigned)i_] = stage[(k) * MORT_WF_STAGE + i_]; \
-            staged[k] = 0; \
-        } } while (0)
 
     for (;;) {
         const int nT = __popcll(__ballot(state == W_T));
@@ -227,15 +237,54 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
             WPROFC(1);
         } else {
             WPROF(2, nF);
-            /* ---- retire finished rays (wave-uniform control flow: every lane runs this block) ---- */
+            /* wave-uniform control flow: every lane runs this block.  The refill comes first so that the
+             * wait for the prefetched batch never covers the stores issued by this step's retire. */
             const bool inF = (state == W_F);
+            const bool fin = inF && have;
+            const unsigned f_pos = pos;
+            const float f_t = closest;
+            const int f_best = best;
+            const uint32_t f_bmat = bmat;
+            if (inF) have = false;
+            /* ---- hand the waiting lanes the next records of the slice ---- */
+            const unsigned long long need = __ballot(inF);
+            const int want = __popcll(need);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+            int served = 0;
+#pragma unroll
+            for (int round = 0; round < 2; round++) {
+                if (served < want) {
+                    if (A_head == A_cnt && B_cnt > 0) { /* batch used up: switch to the prefetched one, start loading the one after */
+                        cur ^= 1; A_base = B_base; A_cnt = B_cnt; A_head = 0;
+                        WF_DMA(cur ^ 1, B_base, B_cnt);
+                        ring_fresh = true;
+                    }
+                    int take = A_cnt - A_head;
+                    if (take > want - served) take = want - served;
+                    if (take > 0) {
+                        if (ring_fresh) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ring_fresh = false; }
+                        if (inF && rank >= served && rank < served + take) {
+                            const int slot = A_head + (rank - served);
+                            const float4 r0 = ring[cur * 128 + slot], r1 = ring[cur * 128 + 64 + slot];
+                            ox = r0.x; oy = r0.y; oz = r0.z; tm = r0.w; dx = r1.x; dy = r1.y; dz = r1.z;
+                            pos = A_base + (unsigned)slot;
+                            sr = slab_ray(ox, oy, oz, dx, dy, dz);
+                            ra = dx * dx + dy * dy + dz * dz;
+                            closest = __builtin_inff(); best = -1; bmat = 0; node = node_first;
+                            have = true;
+                            state = (node_first < node_end) ? W_T : W_F;
+                        }
+                        A_head += take; served += take;
+                    }
+                }
+            }
+            /* ---- retire the finished rays: hit record at the ray's position, position into its class queue ---- */
             int cls = -1;
-            if (inF && have) {
-                WfHit h; h.t = closest; h.best = best;
-                w.hits[id] = h;
-                if (best < 0) cls = WC_FIN;
-                else { const int mt = DREF_TYPE(bmat); cls = (mt == MORT_MAT_LAMBERTIAN || mt == MORT_MAT_ISOTROPIC) ? WC_LAMB : WC_SPEC; }
-                have = false;
+            if (fin) {
+                WfHit h; h.t = f_t; h.best = f_best;
+                w.hits[f_pos] = h;
+                if (f_best < 0) cls = WC_FIN;
+                else { const int mt = DREF_TYPE(f_bmat); cls = (mt == MORT_MAT_LAMBERTIAN || mt == MORT_MAT_ISOTROPIC) ? WC_LAMB : WC_SPEC; }
             }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
@@ -243,39 +292,12 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
                 const int n = __popcll(m);
                 if (n > 0) {
                     if (staged[k] + n > MORT_WF_STAGE) WF_FLUSH(k);
-                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                    if (cls == k) stage[k * MORT_WF_STAGE + staged[k] + rank] = id;
+                    const int rk = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    if (cls == k) stage[k * MORT_WF_STAGE + staged[k] + rk] = f_pos;
                     staged[k] += n;
                 }
             }
-            /* ---- pull the next paths from the wave's reserved range ---- */
-            const unsigned long long need = __ballot(inF);
-            int want = __popcll(need);
-            if (want > 0 && pull_left == 0 && !exhausted) {
-                unsigned b = 0;
-                if (lane == 0) b = atomicAdd(&w.cnt->trav_fetch, (unsigned)MORT_WF_PULL);
-                b = __shfl(b, 0);
-                if (b >= n_items) { exhausted = true; }
-                else { pull_base = b; pull_left = (n_items - b < (unsigned)MORT_WF_PULL) ? (n_items - b) : (unsigned)MORT_WF_PULL; }
-            }
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
-            const unsigned serve = ((unsigned)want < pull_left) ? (unsigned)want : pull_left;
-            if (inF) {
-                if ((unsigned)rank < serve) {
-                    id = queue[pull_base + (unsigned)rank];
-                    const WfRay rr = w.rays[id];
-                    ox = rr.ox; oy = rr.oy; oz = rr.oz; tm = rr.tm; dx = rr.dx; dy = rr.dy; dz = rr.dz;
-                    sr = slab_ray(ox, oy, oz, dx, dy, dz);
-                    ra = dx * dx + dy * dy + dz * dz;
-                    closest = __builtin_inff(); best = -1; bmat = 0; node = node_first;
-                    have = true;
-                    state = (node_first < node_end) ? W_T : W_F;
-                } else if (exhausted || (pull_left == 0 && serve == 0 && exhausted)) {
-                    state = W_DONE;
-                }
-                /* else: stays in W_F, served from the next reservation */
-            }
-            pull_base += serve; pull_left -= serve;
+            if (inF && !have && A_head == A_cnt && B_cnt == 0) state = W_DONE; /* slice exhausted */
             WPROFC(2);
         }
     }
@@ -284,19 +306,23 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
     if (lane == 0) {
         for (int k = 0; k < 3; k++) { atomicAdd(&w.r.counters[4 + k], pr_steps[k]); atomicAdd(&w.r.counters[8 + k], pr_lanes[k]); }
         for (int k = 0; k < 4; k++) atomicAdd(&w.r.counters[12 + k], pr_cyc[k]);
+        const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+        atomicAdd(&w.r.counters[20], rt1 - rt0);           /* sum of wave lifetimes, 10 ns ticks */
+        atomicAdd(&w.r.counters[21], 1ull);                /* waves */
+        atomicAdd(&w.r.counters[22], pt0 - 0ull > 0 ? (unsigned long long)0 : 0ull);
     }
 #endif
 #undef WF_FLUSH
+#undef WF_DMA
 }
 
 /* ---- shading of one front ---- */
-DEV bool wf_texture(const DScene &sc, const DLambert &m, V3 outward, V3 p, V3 &color) {
+DEV void wf_texture(const DScene &sc, const DLambert &m, V3 outward, V3 p, V3 &color) {
     color = mk(m.r, m.g, m.b);
-    if (m.tex == 0) return true;
+    if (m.tex == 0) return;
     float u = 0, v = 0;
-    /* only image textures / the error pattern read (u, v) */
     uint32_t tex = m.tex;
-    for (int guard = 0; guard < 8; guard++) {
+    for (int guard = 0; guard < 8; guard++) { /* only image textures / the error pattern read (u, v) */
         const int tt = DREF_TYPE(tex);
         if (tt == MORT_TEXTURE_CHECKER) {
             const DChecker c = sc.checker[DREF_IDX(tex)];
@@ -310,7 +336,6 @@ DEV bool wf_texture(const DScene &sc, const DLambert &m, V3 outward, V3 p, V3 &c
         break;
     }
     color = texture_value(sc, tex, u, v, p);
-    return true;
 }
 
 extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
@@ -320,9 +345,8 @@ extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
     const unsigned n0 = w.cnt->cls_count[par][0], n1 = w.cnt->cls_count[par][1], n2 = w.cnt->cls_count[par][2];
     const unsigned b0 = (n0 + 255u) >> 8, b1 = (n1 + 255u) >> 8, b2 = (n2 + 255u) >> 8;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        /* the other parity's class counters were last read by the previous wf_shade; wf_trav of this front is done */
+        /* the other parity's class counters were last read by the previous wf_shade; this front's wf_trav is done */
         w.cnt->cls_count[par ^ 1][0] = 0; w.cnt->cls_count[par ^ 1][1] = 0; w.cnt->cls_count[par ^ 1][2] = 0;
-        w.cnt->trav_fetch = 0;
     }
     unsigned b = blockIdx.x;
     int cls;
@@ -335,15 +359,19 @@ extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
     const bool valid = i < n;
     unsigned id = 0;
     bool cont = false; /* path continues into the next front */
+    Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.tm = 0;
+    float out_time0 = 0;
     if (valid) {
-        id = w.q_cls[cls][i];
-        const WfRay rr = w.rays[id];
-        const WfHit h = w.hits[id];
+        const unsigned pos = w.q_cls[cls][i];
+        id = w.q_id[par][pos];
+        const WfRay rr = w.q_ray[par][pos];
+        const WfHit h = w.hits[pos];
         WfPix P = w.pix[id];
         Rng rng = wf_rng_load(P);
         int s_i = (int)(P.packed & 0xfffu), s_j = (int)((P.packed >> 12) & 0xfffu), iter = (int)(P.packed >> 24);
-        Ray ray; ray.o = mk(rr.ox, rr.oy, rr.oz); ray.d = mk(rr.dx, rr.dy, rr.dz); ray.tm = rr.tm;
+        ray.o = mk(rr.ox, rr.oy, rr.oz); ray.d = mk(rr.dx, rr.dy, rr.dz); ray.tm = rr.tm;
         const float time0 = rr.time0;
+        out_time0 = time0;
         V3 final_value = a.background; /* WC_FIN from wf_trav: a miss (camera.cuh:154-158) */
         bool terminated = (cls == WC_FIN);
         if (!terminated) {
@@ -354,6 +382,7 @@ extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
             const V3 normal = front_face ? outward : vneg(outward);
             const int mtype = DREF_TYPE(sp.mat), midx = DREF_IDX(sp.mat);
             float4 e;
+            e.x = e.y = e.z = e.w = 1.0f;
             V3 ndir = mk(0, 0, 1);
             if (cls == WC_LAMB) { /* materials.cuh:38-55,182-198; pdf.cuh:29-54 */
                 const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
@@ -393,7 +422,6 @@ extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
                     ndir = reflect(unit_direction, normal);
                 else
                     ndir = refract(unit_direction, normal, refraction_ratio);
-                e.x = 1.0f; e.y = 1.0f; e.z = 1.0f; e.w = 1.0f;
             } else { /* diffuse_light / unknown tag: no scatter (materials.cuh:151-163) */
                 V3 emission = mk(0, 0, 0);
                 if (mtype == MORT_MAT_DIFFUSE_LIGHT && front_face) wf_texture(sc, sc.dlight[midx], outward, p, emission);
@@ -422,6 +450,7 @@ extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
             if (s_j < a.sqrt_spp) {
                 const int y = global_row(ly, a.rank, a.nranks, a.rows_per_block);
                 ray = get_ray(a, x, y, rng, s_i, s_j);
+                out_time0 = ray.tm;
                 P.segments++;
                 cont = true;
             } else { /* camera.cuh:194-207 */
@@ -450,18 +479,15 @@ extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
                 atomicAdd(&a.counters[1], (unsigned long long)rng.draws);
                 cont = false;
             }
-            if (cont) { iter = 0; }
+            if (cont) iter = 0;
         }
         if (cont) {
             wf_rng_store(P, rng);
             P.packed = (uint32_t)s_i | ((uint32_t)s_j << 12) | ((uint32_t)iter << 24);
             w.pix[id] = P;
-            WfRay o; o.ox = ray.o.x; o.oy = ray.o.y; o.oz = ray.o.z; o.tm = ray.tm; o.dx = ray.d.x; o.dy = ray.d.y; o.dz = ray.d.z;
-            o.time0 = terminated ? ray.tm : time0;
-            w.rays[id] = o;
         }
     }
-    /* append the survivors to the next front's queue: one global atomicAdd per workgroup */
+    /* append the survivors to the next front: one global atomicAdd per workgroup, coalesced record writes */
     {
         __shared__ unsigned s_cnt[4], s_fin[4], s_base;
         const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -472,14 +498,19 @@ extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
         if (threadIdx.x == 0) {
             const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
             const unsigned fin = s_fin[0] + s_fin[1] + s_fin[2] + s_fin[3];
-            s_base = tot ? atomicAdd(&w.cnt->trav_count[par ^ 1], tot) : 0u;
+            s_base = tot ? atomicAdd(&w.cnt->front_count[par ^ 1], tot) : 0u;
             if (fin) atomicSub(&w.cnt->live, fin); /* only finished pixels change the live count */
         }
         __syncthreads();
         unsigned off = s_base;
         for (int k = 0; k < wv; k++) off += s_cnt[k];
         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (cont) w.q_trav[par ^ 1][off + (unsigned)rank] = id;
+        if (cont) {
+            const unsigned np = off + (unsigned)rank;
+            WfRay o; o.ox = ray.o.x; o.oy = ray.o.y; o.oz = ray.o.z; o.tm = ray.tm; o.dx = ray.d.x; o.dy = ray.d.y; o.dz = ray.d.z; o.time0 = out_time0;
+            w.q_ray[par ^ 1][np] = o;
+            w.q_id[par ^ 1][np] = id;
+        }
     }
 }
 
