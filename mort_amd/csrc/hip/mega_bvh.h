@@ -46,23 +46,28 @@ struct FastArgs {
     int node_first, node_count;
     unsigned int *next_q; /* work counter, zeroed before launch */
     int tiles_x, tiles_total;
+    uint32_t off_stack;   /* LDS offset of the per-lane bounce stacks: [depth][thread] float4 */
+    int stack_lds_depth;  /* entries per lane kept in LDS; deeper entries spill to private memory */
 };
 
 enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
 enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 
 #ifndef MORT_TH_S
-#define MORT_TH_S 24
+#define MORT_TH_S 32
 #endif
 #ifndef MORT_TH_L
 #define MORT_TH_L 24
 #endif
 #ifndef MORT_T_KEEP
-#define MORT_T_KEEP 24
+#define MORT_T_KEEP 16
 #endif
 
 #ifndef MORT_MIN_WAVES
 #define MORT_MIN_WAVES 3
+#endif
+#ifndef MORT_FAST_BLOCK
+#define MORT_FAST_BLOCK 768
 #endif
 
 template <int BLOCK, int TH_S, int TH_L, int T_KEEP>
@@ -105,7 +110,9 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
     uint32_t leaf_prims = 0;
     V3 final_value = mk(0, 0, 0);
     unsigned long long tot_segments = 0, tot_draws = 0;
-    StackEntry stack[MORT_MAX_BOUNCE_LIMIT];
+    StackEntry stack_deep[MORT_MAX_BOUNCE_LIMIT]; /* private overflow, touched only by paths deeper than the LDS part */
+    float4 *stack_lds = (float4 *)(lds + fa.off_stack);
+    const int DL = fa.stack_lds_depth;
 #ifdef MORT_PROFILE_STATES
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}; /* steps/lanes for T, L, S (wave-uniform) */
     unsigned long long profc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* cycles in T, L, S, scheduler; S parts: shade, finish, newpix, setup */
@@ -264,7 +271,8 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             kind = K_FINISH;
                         }
                         if (kind == K_SHADE) {
-                            stack[iter] = e;
+                            if (iter < DL) { float4 e4; e4.x = e.kx; e4.y = e.ky; e4.z = e.kz; e4.w = e.rp; stack_lds[iter * BLOCK + threadIdx.x] = e4; }
+                            else stack_deep[iter] = e;
                             iter++;
                             if (iter >= a.bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
                         }
@@ -274,7 +282,9 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                 if (kind == K_FINISH) { /* unwind + accumulate (camera.cuh:165-173,190) */
                     while (iter > 0) {
                         iter--;
-                        const StackEntry e = stack[iter];
+                        StackEntry e;
+                        if (iter < DL) { const float4 e4 = stack_lds[iter * BLOCK + threadIdx.x]; e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w; }
+                        else e = stack_deep[iter];
                         const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
                         final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
                     }

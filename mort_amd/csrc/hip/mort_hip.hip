@@ -847,13 +847,24 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         fa.node_first = 0; fa.node_count = c->sc.n_nodes;
         fa.next_q = (unsigned int *)(c->d_counters + 2);
         fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
-        auto kern = mega_bvh_kernel<256, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>;
+        const int FB = MORT_FAST_BLOCK;
+        auto kern = mega_bvh_kernel<MORT_FAST_BLOCK, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>;
+        /* LDS: hot blob + as many bounce-stack levels per lane as fit next to it (one workgroup per CU) */
+        const uint32_t stack_off = (c->hot_bytes + 15u) & ~15u;
+        int dl = (int)((160u * 1024u - 256u - stack_off) / ((uint32_t)FB * 16u));
+        if (dl > 12) dl = 12;
+        if (dl < 0) dl = 0;
+        fa.off_stack = stack_off; fa.stack_lds_depth = dl;
+        const size_t lds_bytes = (size_t)stack_off + (size_t)dl * FB * 16;
+        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, c->hot_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, FB, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
         int grid = c->num_cus * per_cu;
-        if (grid > blocks) grid = blocks;
-        lds_bytes_used = (int)c->hot_bytes;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), c->hot_bytes, s, fa);
+        const int want_blocks = (tiles * 64 + FB - 1) / FB;
+        if (grid > want_blocks) grid = want_blocks;
+        if (grid < 1) grid = 1;
+        lds_bytes_used = (int)lds_bytes;
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(FB), lds_bytes, s, fa);
         HIPCHK(c, hipGetLastError());
     } else if (blocks > 0) {
         hipLaunchKernelGGL(mega_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, s, a);
@@ -899,7 +910,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         stats->local_rows = a.local_rows;
         hipFuncAttributes fattr;
         const void *kf = mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
-                         : (use_v1 ? (const void *)mega_bvh_kernel<256, MORT_TH_S, MORT_TH_L, MORT_T_KEEP> : (const void *)mega_bvh2_kernel<MORT2_BLOCK, MORT2_TH_T>);
+                         : (use_v1 ? (const void *)mega_bvh_kernel<MORT_FAST_BLOCK, MORT_TH_S, MORT_TH_L, MORT_T_KEEP> : (const void *)mega_bvh2_kernel<MORT2_BLOCK, MORT2_TH_T>);
         if (hipFuncGetAttributes(&fattr, kf) == hipSuccess) {
             stats->kernel_vgprs = fattr.numRegs;
             stats->kernel_lds_bytes = use_fast ? lds_bytes_used : (int)fattr.sharedSizeBytes;
