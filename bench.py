@@ -146,6 +146,16 @@ def main():
         pixels_launch = W * lr
         algo_bytes = 100 * pixels_launch  # 48 B state in + 48 B out + 4 B uchar4 per pixel; 0 B per segment
         achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
+        # HBM traffic from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process);
+        # only quoted when this run is the profiled configuration
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "v2_pmc_hbm.json")))
+            cfg = pm["config"]
+            if (args.scene, W, H, args.spp, world_size) == (cfg["scene"], cfg["width"], cfg["height"], cfg["spp"], cfg["gpus"]):
+                traffic = pm["traffic_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "Msamples/sec (width x height x spp/s), Scene 1 1200x675",
             "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -156,9 +166,10 @@ def main():
                        "mode": "mega", "partition": f"rows/{args.rows_per_block} interleaved over {world_size} rank(s)",
                        "nominal_msamples_per_s": W * H * args.spp * args.steps / elapsed_max / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mega_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "mega_bvh_kernel" if st["scene_in_lds"] else "mega_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes,
+                         "traffic_source": "profiles/r1/v2_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
                          "note": "megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
                                  "so the HBM fraction is tiny and the kernel is VALU/latency bound (DESIGN.md)"},
             "kernel": {"segments_per_frame": st["segments"], "segments_per_s": st["segments"] / st["seconds"],
