@@ -7,6 +7,9 @@
 #ifndef MORT_SCENE_COMPILE_H
 #define MORT_SCENE_COMPILE_H
 
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -200,6 +203,100 @@ struct Compiler {
         out.nodes[id].prims = prims;
     }
 
+    /* ---- this build's own acceleration of large linear runs (world.cuh:122-136 and hittable_list::hit scan every
+     * primitive).  The closest hit of a run does not depend on visiting order once ties are resolved the way the
+     * scan resolves them (a later primitive replaces an equal t), so a BVH over the run gives the same answer as
+     * long as its boxes never hide a primitive the scan would accept: boxes are padded and the device prunes with
+     * a relative margin well above the evaluation error of sphere::hit / quad::hit (dev_trace.h, run_accel). ---- */
+    struct Box { float lo[3], hi[3]; };
+    static Box box_pad(Box b) {
+        for (int k = 0; k < 3; k++) {
+            float ext = b.hi[k] - b.lo[k];
+            float mag = std::fabs(b.lo[k]) > std::fabs(b.hi[k]) ? std::fabs(b.lo[k]) : std::fabs(b.hi[k]);
+            float pad = 1e-3f * ext + 1e-4f * mag + 1e-4f;
+            b.lo[k] -= pad; b.hi[k] += pad;
+        }
+        return b;
+    }
+    Box prim_box(int kind, int idx) const {
+        Box b;
+        if (kind == ITEM_SPHERES) {
+            const DSphere &s = out.spheres[idx];
+            const float c0[3] = {s.cx, s.cy, s.cz}, c1[3] = {s.cx + s.vx, s.cy + s.vy, s.cz + s.vz};
+            for (int k = 0; k < 3; k++) {
+                b.lo[k] = std::fmin(c0[k], c1[k]) - s.radius;
+                b.hi[k] = std::fmax(c0[k], c1[k]) + s.radius;
+            }
+        } else {
+            const DQuad &q = out.quads[idx];
+            for (int k = 0; k < 3; k++) {
+                const float p0 = q.Q[k], p1 = q.Q[k] + q.u[k], p2 = q.Q[k] + q.v[k], p3 = q.Q[k] + q.u[k] + q.v[k];
+                b.lo[k] = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3));
+                b.hi[k] = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
+            }
+        }
+        return box_pad(b);
+    }
+    void accel_emit(int kind, std::vector<int> &ids, const std::vector<Box> &boxes, int lo, int hi) {
+        const size_t id = out.nodes.size();
+        Box u = boxes[ids[lo]];
+        float cmin[3], cmax[3];
+        for (int k = 0; k < 3; k++) { cmin[k] = 1e30f; cmax[k] = -1e30f; }
+        for (int i = lo; i < hi; i++) {
+            const Box &b = boxes[ids[i]];
+            for (int k = 0; k < 3; k++) {
+                u.lo[k] = std::fmin(u.lo[k], b.lo[k]); u.hi[k] = std::fmax(u.hi[k], b.hi[k]);
+                const float c = 0.5f * (b.lo[k] + b.hi[k]);
+                cmin[k] = std::fmin(cmin[k], c); cmax[k] = std::fmax(cmax[k], c);
+            }
+        }
+        DBvhNode nd;
+        std::memset(&nd, 0, sizeof nd);
+        nd.xmin = u.lo[0]; nd.xmax = u.hi[0]; nd.ymin = u.lo[1]; nd.ymax = u.hi[1]; nd.zmin = u.lo[2]; nd.zmax = u.hi[2];
+        out.nodes.push_back(nd);
+        const int n = hi - lo;
+        bool leaf = n <= 2;
+        uint32_t prims = 0;
+        if (leaf) {
+            const uint32_t kbit = (kind == ITEM_QUADS) ? 0x8000u : 0u;
+            const uint32_t pa = kbit | (uint32_t)ids[lo], pb = kbit | (uint32_t)ids[hi - 1];
+            prims = pa | (pb << 16);
+        } else {
+            int axis = 0;
+            if (cmax[1] - cmin[1] > cmax[axis] - cmin[axis]) axis = 1;
+            if (cmax[2] - cmin[2] > cmax[axis] - cmin[axis]) axis = 2;
+            const int mid = lo + n / 2;
+            std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [&](int a, int b) {
+                const float ca = boxes[a].lo[axis] + boxes[a].hi[axis], cb = boxes[b].lo[axis] + boxes[b].hi[axis];
+                return ca < cb || (ca == cb && a < b);
+            });
+            accel_emit(kind, ids, boxes, lo, mid);
+            accel_emit(kind, ids, boxes, mid, hi);
+        }
+        out.nodes[id].skip = (uint32_t)out.nodes.size() | (leaf ? 0x80000000u : 0u);
+        out.nodes[id].prims = prims;
+    }
+    void build_accels(std::vector<DItem> &items) {
+        for (DItem &it : items) {
+            it.accel_first = 0;
+            if (it.kind != ITEM_SPHERES && it.kind != ITEM_QUADS) continue;
+            it.medium = 0; /* accel_count */
+            if (it.count < 16 || it.first + it.count > 0x7fff) continue;
+            std::vector<Box> boxes(it.first + it.count);
+            std::vector<int> ids;
+            bool finite = true;
+            for (int i = it.first; i < it.first + it.count; i++) {
+                boxes[i] = prim_box(it.kind, i);
+                for (int k = 0; k < 3; k++) if (!std::isfinite(boxes[i].lo[k]) || !std::isfinite(boxes[i].hi[k])) finite = false;
+                ids.push_back(i);
+            }
+            if (!finite) continue;
+            it.accel_first = (int)out.nodes.size();
+            accel_emit(it.kind, ids, boxes, 0, (int)ids.size());
+            it.medium = (int)out.nodes.size() - it.accel_first;
+        }
+    }
+
     static uint32_t tex_ref(int type, int idx) { return DREF(type & 0x7fff, idx & 0xffff); }
 
     DLambert tex_material(int tex_type, int tex_idx) {
@@ -234,6 +331,9 @@ struct Compiler {
             for (int i = 0; i < o.num_hittable_list; i++) if (!o.host_hittable_list[i].skip) flatten(MORT_OBJ_HITTABLE_LIST, i, 0, 0, 0, refs);
             emit_items(refs, out.items, true);
         }
+        if (!std::getenv("MORT_NO_ACCEL")) { build_accels(out.items); build_accels(out.subitems); }
+        else { for (DItem &it : out.items) { it.accel_first = 0; if (it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) it.medium = 0; }
+               for (DItem &it : out.subitems) { it.accel_first = 0; if (it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) it.medium = 0; } }
         /* world-order copies for light sampling */
         for (int i = 0; i < o.num_spheres; i++) out.wspheres.push_back(to_dsphere(o.host_sphere[i]));
         for (int i = 0; i < o.num_quads; i++) out.wquads.push_back(to_dquad(o.host_quad[i]));

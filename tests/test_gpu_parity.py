@@ -74,6 +74,24 @@ def test_generic_kernel_on_bvh_scene(gpu_ctx, oracle, monkeypatch):
     assert_same(out, ref)
 
 
+@pytest.mark.parametrize("sid,width,spp,depth", [(9, 120, 9, None), (8, 72, 4, None), (8, 64, 4, 6)])
+def test_accelerated_runs_equal_linear_scan(oracle, monkeypatch, sid, width, spp, depth):
+    """final_scene scans 2401 quads + a 1000-sphere list per ray in the reference; this build walks its own BVH
+    over such runs (scene_compile.h build_accels).  Both forms must give the oracle's bits."""
+    world, cam = host.build_scene(sid, width=width, spp=spp, depth=depth)
+    ref = oracle.render(world, cam, nthreads=16)
+    for no_accel in (False, True):
+        if no_accel:
+            monkeypatch.setenv("MORT_NO_ACCEL", "1")
+        else:
+            monkeypatch.delenv("MORT_NO_ACCEL", raising=False)
+        ctx = hip.Context(0)
+        try:
+            assert_same(render_gpu(ctx, world, cam, oracle=oracle), ref)
+        finally:
+            ctx.close()
+
+
 @pytest.mark.parametrize("depth", [0, 1, 2, 50])
 def test_bounce_limits(gpu_ctx, oracle, depth):
     world, cam = host.build_scene(1, width=96, spp=4, depth=depth)
