@@ -327,7 +327,6 @@ seed_kernel(const SeedArgs a) {
 }
 
 #include "mega_bvh.h"
-#include "mega_bvh2.h"
 #include "wave_bvh.h"
 
 /* ====================================================================== host */
@@ -361,8 +360,6 @@ struct mort_ctx {
              off_solid = 0, off_checker = 0, hot_bytes = 0;
     bool fast_ok = false;
     int num_cus = 256;
-    float4 *d_stack_ovf = nullptr; /* mega_bvh2: HBM overflow of the LDS bounce stacks */
-    size_t stack_ovf_paths = 0;
     /* wavefront mode work buffers */
     void *d_wf = nullptr;
     size_t wf_bytes = 0;
@@ -466,7 +463,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->d_scene); hipFree(c->d_states); hipFree(c->d_seqmats);
-    hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_stack_ovf); hipFree(c->d_wf);
+    hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
     if (c->h_live) hipHostFree(c->h_live);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -786,10 +783,8 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     const int waves_per_block = 4;
     const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
     const char *force = std::getenv("MORT_FORCE_GENERIC");
-    const char *variant = std::getenv("MORT_FAST_VARIANT");
     const bool use_fast = c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->bounce_limit >= 1 &&
                           !(force && force[0] == '1');
-    const bool use_v1 = use_fast && !(variant && variant[0] == '2'); /* MORT_FAST_VARIANT=2: two-paths-per-lane kernel */
     int lds_bytes_used = 0;
     if (mode == MORT_MODE_WAVE) {
         /* the wavefront pipeline covers: one BVH of spheres as the world, no light object */
@@ -801,42 +796,6 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         int st_w = render_wavefront(c, a, cam, s);
         if (st_w != MORT_OK) return st_w;
         lds_bytes_used = (int)c->hot_bytes;
-    } else if (blocks > 0 && use_fast && !use_v1) {
-        const int BLOCK = MORT2_BLOCK;
-        Fast2Args fa;
-        std::memset(&fa, 0, sizeof fa);
-        fa.r = a;
-        fa.hot_src = (const unsigned char *)c->d_scene; fa.hot_bytes = c->hot_bytes;
-        fa.off_nodes = c->off_nodes; fa.off_spheres = c->off_spheres; fa.off_lambert = c->off_lambert; fa.off_metal = c->off_metal;
-        fa.off_diel = c->off_diel; fa.off_dlight = c->off_dlight; fa.off_iso = c->off_iso; fa.off_solid = c->off_solid; fa.off_checker = c->off_checker;
-        fa.node_first = 0; fa.node_count = c->sc.n_nodes;
-        fa.next_q = (unsigned int *)(c->d_counters + 2);
-        fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
-        const int lds_total = 160 * 1024;
-        int dl = (lds_total - (int)c->hot_bytes - 512) / (2 * BLOCK * 16);
-        if (dl > 8) dl = 8;
-        if (dl < 0) dl = 0;
-        fa.off_stack = c->hot_bytes;
-        fa.stack_lds_depth = dl;
-        const size_t lds_bytes = (size_t)c->hot_bytes + (size_t)dl * 2 * BLOCK * 16;
-        lds_bytes_used = (int)lds_bytes;
-        auto kern = mega_bvh2_kernel<MORT2_BLOCK, MORT2_TH_T>;
-        HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
-        long long want = ((long long)tiles * 64 + (long long)BLOCK * 2 - 1) / ((long long)BLOCK * 2);
-        int grid = c->num_cus * per_cu;
-        if ((long long)grid > want) grid = (int)want;
-        if (grid < 1) grid = 1;
-        const size_t paths = (size_t)grid * BLOCK * 2;
-        if (c->stack_ovf_paths < paths) {
-            if (c->d_stack_ovf) { hipFree(c->d_stack_ovf); c->d_stack_ovf = nullptr; c->stack_ovf_paths = 0; }
-            HIPCHK(c, hipMalloc((void **)&c->d_stack_ovf, paths * MORT_MAX_BOUNCE_LIMIT * sizeof(float4)));
-            c->stack_ovf_paths = paths;
-        }
-        fa.stack_ovf = c->d_stack_ovf;
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds_bytes, s, fa);
-        HIPCHK(c, hipGetLastError());
     } else if (blocks > 0 && use_fast) {
         FastArgs fa;
         std::memset(&fa, 0, sizeof fa);
@@ -888,14 +847,6 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             std::fprintf(stderr, "[wf_trav sched] cycles %5.1f%%   fronts %d\n", 100.0 * (double)cnt[15] / tot, c->wf_fronts);
             std::fprintf(stderr, "[wf_trav waves] %llu waves, mean lifetime %.1f us, in-loop cycles per wave %.0f\n", cnt[21],
                          cnt[21] ? (double)cnt[20] / (double)cnt[21] * 0.01 : 0.0, cnt[21] ? tot / (double)cnt[21] : 0.0);
-        } else if (use_fast && !use_v1) {
-            const char *nm[6] = {"sched", "FIN", "SPEC", "LAMB", "L", "T"};
-            double tot = 0;
-            for (int k = 0; k < 6; k++) tot += (double)cnt[16 + k];
-            for (int k = 5; k >= 0; k--)
-                std::fprintf(stderr, "[v3 %-5s] %10llu wave-steps  util %5.1f%%  cycles %5.1f%%  (%.0f/step)\n", nm[k], cnt[4 + k],
-                             cnt[4 + k] ? 100.0 * (double)cnt[10 + k] / (64.0 * (double)cnt[4 + k]) : 0.0, 100.0 * (double)cnt[16 + k] / tot,
-                             cnt[4 + k] ? (double)cnt[16 + k] / (double)cnt[4 + k] : 0.0);
         }
 #endif
         std::memset(stats, 0, sizeof *stats);
@@ -910,7 +861,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         stats->local_rows = a.local_rows;
         hipFuncAttributes fattr;
         const void *kf = mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
-                         : (use_v1 ? (const void *)mega_bvh_kernel<MORT_FAST_BLOCK, MORT_TH_S, MORT_TH_L, MORT_T_KEEP> : (const void *)mega_bvh2_kernel<MORT2_BLOCK, MORT2_TH_T>);
+                         : (const void *)mega_bvh_kernel<MORT_FAST_BLOCK, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>;
         if (hipFuncGetAttributes(&fattr, kf) == hipSuccess) {
             stats->kernel_vgprs = fattr.numRegs;
             stats->kernel_lds_bytes = use_fast ? lds_bytes_used : (int)fattr.sharedSizeBytes;
@@ -944,6 +895,12 @@ extern "C" int mort_hip_render(mort_ctx *c, const mort_camera *cam, int mode, ui
     st = mort_hip_render_device(c, cam, mode, c->d_rgba, accum_out ? c->d_accum : nullptr, nullptr, &local);
     if (st != MORT_OK) return st;
     if (stats) *stats = local;
+    if (c->part.nranks == 1) { /* packed rows are the whole image: three copies instead of one per row */
+        HIPCHK(c, hipMemcpy(rgba_out, c->d_rgba, npx * 4, hipMemcpyDeviceToHost));
+        if (accum_out) HIPCHK(c, hipMemcpy(accum_out, c->d_accum, npx * 12, hipMemcpyDeviceToHost));
+        if (segments_px_out) HIPCHK(c, hipMemcpy(segments_px_out, c->d_segpx, npx * 4, hipMemcpyDeviceToHost));
+        return MORT_OK;
+    }
     for (int ly = 0; ly < lr; ly++) {
         const int y = global_row_host(c->part, ly);
         HIPCHK(c, hipMemcpy(rgba_out + (size_t)y * W * 4, (uint8_t *)c->d_rgba + (size_t)ly * W * 4, (size_t)W * 4, hipMemcpyDeviceToHost));
