@@ -48,6 +48,11 @@ struct FastArgs {
     int tiles_x, tiles_total;
     uint32_t off_stack;   /* LDS offset of the per-lane bounce stacks: [depth][thread] float4 */
     int stack_lds_depth;  /* entries per lane kept in LDS; deeper entries spill to private memory */
+    const unsigned *tile_order; /* tiles in the order lanes should take them (most expensive first), or null = row-major */
+    unsigned *tile_cost;        /* per tile: segments traced this frame (feeds the next frame's order), or null */
+    int probe;                  /* 1: cost probe -- trace, accumulate tile_cost, write no image / state */
+    int th_s, th_l, t_keep; /* scheduling thresholds (lanes): batch sizes that trigger a shade / leaf step, and the
+                               lane count below which the box-step loop hands control back (wave-uniform) */
 };
 
 enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
@@ -71,7 +76,7 @@ enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 #endif
 
 template <int BLOCK, int TH_S, int TH_L, int T_KEEP>
-__global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
+__global__ void __launch_bounds__(BLOCK, (MORT_MIN_WAVES * BLOCK + 767) / 768 > 0 ? MORT_MIN_WAVES : 1) mega_bvh_kernel(const FastArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const RenderArgs &a = fa.r;
     {
@@ -92,6 +97,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
     const DChecker *checker = (const DChecker *)(lds + fa.off_checker);
 
     const int node_first = fa.node_first, node_end = fa.node_first + fa.node_count;
+    const int th_s = fa.th_s, th_l = fa.th_l, t_keep = fa.t_keep;
     const int spp = a.sqrt_spp * a.sqrt_spp;
     const unsigned total_q = (unsigned)fa.tiles_total * 64u;
 
@@ -136,8 +142,8 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
         if ((mT | mL | mS) == 0ull) break;
         const int nT = __popcll(mT), nL = __popcll(mL), nS = __popcll(mS);
         int pick;
-        if (nS >= TH_S) pick = ST_S;
-        else if (nL >= TH_L) pick = ST_L;
+        if (nS >= th_s) pick = ST_S;
+        else if (nL >= th_l) pick = ST_L;
         else if (nT > 0) pick = ST_T;
         else pick = (nL >= nS) ? ST_L : ST_S;
         PROFC(3);
@@ -163,7 +169,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     if (state == ST_T && node >= node_end) { state = ST_S; kind = K_SHADE; }
                 }
                 keep = __popcll(__ballot(state == ST_T));
-            } while (keep >= T_KEEP);
+            } while (keep >= t_keep);
             PROFC(0);
         } else if (pick == ST_L) {
             /* ---- leaf: sphere::hit on one or two spheres (objects.cuh:60-77,690-692) ---- */
@@ -299,23 +305,29 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         if (c.x != c.x) c.x = 0.0f;
                         if (c.y != c.y) c.y = 0.0f;
                         if (c.z != c.z) c.z = 0.0f;
-                        if (a.accum) { a.accum[3 * lofs] = c.x; a.accum[3 * lofs + 1] = c.y; a.accum[3 * lofs + 2] = c.z; }
-                        float g[3] = {mort_sqrtf(c.x), mort_sqrtf(c.y), mort_sqrtf(c.z)};
-                        unsigned char b[3];
-#pragma unroll
-                        for (int k = 0; k < 3; k++) {
-                            float v = g[k];
-                            if (v < 0.0f) v = 0.0f;
-                            if (v > 0.999f) v = 0.999f;
-                            b[k] = (unsigned char)mort_f2i(256 * v);
+                        if (fa.tile_cost) {
+                            const int lyl = lofs / a.width, xl = lofs - lyl * a.width;
+                            atomicAdd(&fa.tile_cost[(lyl >> 3) * fa.tiles_x + (xl >> 3)], segments);
                         }
-                        uchar4 out; out.x = b[0]; out.y = b[1]; out.z = b[2]; out.w = 255;
-                        a.rgba[lofs] = out;
-                        if (a.seg_px) a.seg_px[lofs] = segments;
-                        mort_rng_state st;
-                        st.d = rng.d; st.v[0] = rng.v0; st.v[1] = rng.v1; st.v[2] = rng.v2; st.v[3] = rng.v3; st.v[4] = rng.v4;
-                        st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
-                        a.states[lofs] = st;
+                        if (!fa.probe) {
+                            if (a.accum) { a.accum[3 * lofs] = c.x; a.accum[3 * lofs + 1] = c.y; a.accum[3 * lofs + 2] = c.z; }
+                            float g[3] = {mort_sqrtf(c.x), mort_sqrtf(c.y), mort_sqrtf(c.z)};
+                            unsigned char b[3];
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                float v = g[k];
+                                if (v < 0.0f) v = 0.0f;
+                                if (v > 0.999f) v = 0.999f;
+                                b[k] = (unsigned char)mort_f2i(256 * v);
+                            }
+                            uchar4 out; out.x = b[0]; out.y = b[1]; out.z = b[2]; out.w = 255;
+                            a.rgba[lofs] = out;
+                            if (a.seg_px) a.seg_px[lofs] = segments;
+                            mort_rng_state st;
+                            st.d = rng.d; st.v[0] = rng.v0; st.v[1] = rng.v1; st.v[2] = rng.v2; st.v[3] = rng.v3; st.v[4] = rng.v4;
+                            st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
+                            a.states[lofs] = st;
+                        }
                         tot_segments += segments; tot_draws += rng.draws;
                         kind = K_NEWPIX;
                     }
@@ -333,7 +345,8 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         base = __shfl(base, __ffsll((long long)need) - 1);
                         const unsigned q = base + (unsigned)rank;
                         if (q >= total_q) { state = ST_DONE; got = true; break; }
-                        const int tile = (int)(q >> 6), within = (int)(q & 63u);
+                        const int tslot = (int)(q >> 6), within = (int)(q & 63u);
+                        const int tile = fa.tile_order ? (int)fa.tile_order[tslot] : tslot;
                         const int tx = tile % fa.tiles_x, ty = tile / fa.tiles_x;
                         const int qx = tx * 8 + (within & 7), qly = ty * 8 + (within >> 3);
                         if (qx < a.width && qly < a.local_rows) {

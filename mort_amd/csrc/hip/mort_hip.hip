@@ -15,6 +15,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -360,6 +361,13 @@ struct mort_ctx {
              off_solid = 0, off_checker = 0, hot_bytes = 0;
     bool fast_ok = false;
     int num_cus = 256;
+    /* pixel-tile ordering of the BVH megakernel: most expensive tiles first (cost = segments of the previous
+     * frame with this geometry, or of a 1-sample probe) so the frame does not end on its longest pixel chains */
+    unsigned *d_tile_cost = nullptr, *d_tile_order = nullptr;
+    mort_rng_state *d_probe_states = nullptr;
+    size_t tile_cap = 0, probe_cap = 0;
+    long long cost_key = -1; /* identifies the (geometry, partition, camera) the costs in d_tile_cost belong to */
+    std::vector<unsigned> h_cost, h_order;
     /* wavefront mode work buffers */
     void *d_wf = nullptr;
     size_t wf_bytes = 0;
@@ -464,6 +472,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     hipFree(c->d_scene); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
+    hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states);
     if (c->h_live) hipHostFree(c->h_live);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -786,6 +795,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     const bool use_fast = c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->bounce_limit >= 1 &&
                           !(force && force[0] == '1');
     int lds_bytes_used = 0;
+    const void *fast_kernel_used = nullptr;
     if (mode == MORT_MODE_WAVE) {
         /* the wavefront pipeline covers: one BVH of spheres as the world, no light object */
         if (!(c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1))
@@ -806,11 +816,38 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         fa.node_first = 0; fa.node_count = c->sc.n_nodes;
         fa.next_q = (unsigned int *)(c->d_counters + 2);
         fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
-        const int FB = MORT_FAST_BLOCK;
-        auto kern = mega_bvh_kernel<MORT_FAST_BLOCK, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>;
-        /* LDS: hot blob + as many bounce-stack levels per lane as fit next to it (one workgroup per CU) */
+        /* workgroup size: the largest of {768, 512, 384, 256} that still gives every CU a workgroup
+         * (a rank of an 8-way partition owns ~100 k pixels: 768-thread groups would leave half the CUs idle) */
+        const long long lanes_wanted = (long long)tiles * 64;
+        int FB = MORT_FAST_BLOCK;
+        const char *fb_env = std::getenv("MORT_FAST_BLOCK_SIZE");
+        if (fb_env) FB = std::atoi(fb_env);
+        else {
+            const int cand[4] = {768, 512, 384, 256};
+            FB = 256;
+            for (int k = 0; k < 4; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; }
+        }
+        void (*kern)(const FastArgs) = nullptr;
+        switch (FB) {
+        case 768: kern = mega_bvh_kernel<768, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>; break;
+        case 512: kern = mega_bvh_kernel<512, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>; break;
+        case 384: kern = mega_bvh_kernel<384, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>; break;
+        default: FB = 256; kern = mega_bvh_kernel<256, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>; break;
+        }
+        /* scheduling thresholds: batch for throughput when every lane has several pixels queued behind it, react fast
+         * (small batches) when a rank owns about one pixel per lane and the frame is bound by its longest pixel chain */
+        {
+            const double px_per_lane = (double)lanes_wanted / ((double)c->num_cus * 768.0);
+            fa.th_s = MORT_TH_S; fa.th_l = MORT_TH_L; fa.t_keep = MORT_T_KEEP;
+            if (px_per_lane < 1.5) { fa.th_s = 12; fa.th_l = 12; fa.t_keep = 8; }
+            else if (px_per_lane < 2.5) { fa.th_s = 24; fa.th_l = 16; fa.t_keep = 12; }
+            const char *th = std::getenv("MORT_THRESHOLDS"); /* "s,l,k" */
+            if (th) { int s_ = 0, l_ = 0, k_ = 0; if (std::sscanf(th, "%d,%d,%d", &s_, &l_, &k_) == 3) { fa.th_s = s_; fa.th_l = l_; fa.t_keep = k_; } }
+        }
+        /* LDS: hot blob + as many bounce-stack levels per lane as fit next to it (768 threads: one workgroup per CU) */
         const uint32_t stack_off = (c->hot_bytes + 15u) & ~15u;
-        int dl = (int)((160u * 1024u - 256u - stack_off) / ((uint32_t)FB * 16u));
+        const int groups_per_cu = 768 / FB; /* keep 12 waves per CU */
+        int dl = (int)(((160u * 1024u - 256u) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
         if (dl > 12) dl = 12;
         if (dl < 0) dl = 0;
         fa.off_stack = stack_off; fa.stack_lds_depth = dl;
@@ -819,10 +856,54 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, FB, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
         int grid = c->num_cus * per_cu;
-        const int want_blocks = (tiles * 64 + FB - 1) / FB;
+        const int want_blocks = (int)((lanes_wanted + FB - 1) / FB);
         if (grid > want_blocks) grid = want_blocks;
         if (grid < 1) grid = 1;
         lds_bytes_used = (int)lds_bytes;
+        fast_kernel_used = (const void *)kern;
+        /* ---- tile order: expensive tiles first ---- */
+        const bool want_order = !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid;
+        if (want_order) {
+            if (c->tile_cap < (size_t)tiles) {
+                if (c->d_tile_cost) { hipFree(c->d_tile_cost); hipFree(c->d_tile_order); c->d_tile_cost = c->d_tile_order = nullptr; c->tile_cap = 0; }
+                HIPCHK(c, hipMalloc((void **)&c->d_tile_cost, (size_t)tiles * sizeof(unsigned)));
+                HIPCHK(c, hipMalloc((void **)&c->d_tile_order, (size_t)tiles * sizeof(unsigned)));
+                c->tile_cap = (size_t)tiles;
+                c->cost_key = -1;
+            }
+            long long key = (long long)W * 1000003LL + (long long)a.local_rows * 10007LL + (long long)a.rank * 101LL + a.nranks;
+            key = key * 31 + cam->bounce_limit;
+            key = key * 31 + (long long)(cam->lookfrom.e[0] * 1024.0f) + (long long)(cam->lookfrom.e[2] * 7.0f) + (long long)(cam->lookat.e[0] * 3.0f) + cam->vfov;
+            if (c->cost_key != key) { /* no history for this view: one-sample probe on a scratch copy of the streams */
+                const size_t npx = (size_t)W * (size_t)a.local_rows;
+                if (c->probe_cap < npx) {
+                    if (c->d_probe_states) { hipFree(c->d_probe_states); c->d_probe_states = nullptr; c->probe_cap = 0; }
+                    HIPCHK(c, hipMalloc((void **)&c->d_probe_states, npx * sizeof(mort_rng_state)));
+                    c->probe_cap = npx;
+                }
+                HIPCHK(c, hipMemcpyAsync(c->d_probe_states, c->d_states, npx * sizeof(mort_rng_state), hipMemcpyDeviceToDevice, s));
+                HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
+                FastArgs pa = fa;
+                pa.r.states = c->d_probe_states; pa.r.sqrt_spp = 1; pa.r.recip_sqrt_spp = 1.0f; pa.r.pixel_samples_scale = 1.0f;
+                pa.r.accum = nullptr; pa.r.seg_px = nullptr;
+                pa.tile_order = nullptr; pa.tile_cost = c->d_tile_cost; pa.probe = 1;
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(FB), lds_bytes, s, pa);
+                HIPCHK(c, hipGetLastError());
+                HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
+                c->cost_key = key;
+            }
+            /* order = argsort(cost, descending); 12.6 k tiles for the headline frame: done on the host */
+            c->h_cost.resize((size_t)tiles); c->h_order.resize((size_t)tiles);
+            HIPCHK(c, hipMemcpyAsync(c->h_cost.data(), c->d_tile_cost, (size_t)tiles * sizeof(unsigned), hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipStreamSynchronize(s));
+            for (int i = 0; i < tiles; i++) c->h_order[i] = (unsigned)i;
+            const unsigned *cost = c->h_cost.data();
+            std::stable_sort(c->h_order.begin(), c->h_order.end(), [cost](unsigned x, unsigned y) { return cost[x] > cost[y]; });
+            HIPCHK(c, hipMemcpyAsync(c->d_tile_order, c->h_order.data(), (size_t)tiles * sizeof(unsigned), hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
+            fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost; fa.probe = 0;
+            if (stats) HIPCHK(c, hipEventRecord(c->ev0, s)); /* time the frame itself; ordering upkeep is reported by wall-clock benches */
+        }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FB), lds_bytes, s, fa);
         HIPCHK(c, hipGetLastError());
     } else if (blocks > 0) {
@@ -847,6 +928,17 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             std::fprintf(stderr, "[wf_trav sched] cycles %5.1f%%   fronts %d\n", 100.0 * (double)cnt[15] / tot, c->wf_fronts);
             std::fprintf(stderr, "[wf_trav waves] %llu waves, mean lifetime %.1f us, in-loop cycles per wave %.0f\n", cnt[21],
                          cnt[21] ? (double)cnt[20] / (double)cnt[21] * 0.01 : 0.0, cnt[21] ? tot / (double)cnt[21] : 0.0);
+        } else if (use_fast) {
+            const char *nm[3] = {"T", "L", "S"};
+            for (int k = 0; k < 3; k++)
+                std::fprintf(stderr, "[states] %s: %llu wave-steps, %llu lane-steps, utilisation %.1f%%\n", nm[k], cnt[4 + 2 * k], cnt[5 + 2 * k],
+                             cnt[4 + 2 * k] ? 100.0 * (double)cnt[5 + 2 * k] / (64.0 * (double)cnt[4 + 2 * k]) : 0.0);
+            const double tot = (double)(cnt[10] + cnt[11] + cnt[12] + cnt[13]);
+            std::fprintf(stderr, "[cycles] T %.1f%% (%.0f/step)  L %.1f%% (%.0f/step)  S %.1f%% (%.0f/step)  sched %.1f%%  total wave-cycles %.3g\n",
+                         100.0 * cnt[10] / tot, (double)cnt[10] / (double)cnt[4], 100.0 * cnt[11] / tot, (double)cnt[11] / (double)cnt[6],
+                         100.0 * cnt[12] / tot, (double)cnt[12] / (double)cnt[8], 100.0 * cnt[13] / tot, tot);
+            std::fprintf(stderr, "[S parts, cycles/step] shade %.0f  finish %.0f  newpix %.0f  newsample+setup %.0f\n", (double)cnt[14] / (double)cnt[8],
+                         (double)cnt[15] / (double)cnt[8], (double)cnt[16] / (double)cnt[8], (double)cnt[17] / (double)cnt[8]);
         }
 #endif
         std::memset(stats, 0, sizeof *stats);
@@ -861,7 +953,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         stats->local_rows = a.local_rows;
         hipFuncAttributes fattr;
         const void *kf = mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
-                         : (const void *)mega_bvh_kernel<MORT_FAST_BLOCK, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>;
+                         : fast_kernel_used;
         if (hipFuncGetAttributes(&fattr, kf) == hipSuccess) {
             stats->kernel_vgprs = fattr.numRegs;
             stats->kernel_lds_bytes = use_fast ? lds_bytes_used : (int)fattr.sharedSizeBytes;
