@@ -50,7 +50,6 @@ struct FastArgs {
     int stack_lds_depth;  /* entries per lane kept in LDS; deeper entries spill to private memory */
     const unsigned *tile_order; /* tiles in the order lanes should take them (most expensive first), or null = row-major */
     unsigned *tile_cost;        /* per tile: segments traced this frame (feeds the next frame's order), or null */
-    int probe;                  /* 1: cost probe -- trace, accumulate tile_cost, write no image / state */
     int th_s, th_l, t_keep; /* scheduling thresholds (lanes): batch sizes that trigger a shade / leaf step, and the
                                lane count below which the box-step loop hands control back (wave-uniform) */
 };
@@ -75,8 +74,9 @@ enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 #define MORT_FAST_BLOCK 768
 #endif
 
-template <int BLOCK, int TH_S, int TH_L, int T_KEEP>
-__global__ void __launch_bounds__(BLOCK, (MORT_MIN_WAVES * BLOCK + 767) / 768 > 0 ? MORT_MIN_WAVES : 1) mega_bvh_kernel(const FastArgs fa) {
+/* PROBE = true is the 1-sample cost probe (its own symbol, so profiles keep the frame kernel's durations apart) */
+template <int BLOCK, bool PROBE>
+__global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const RenderArgs &a = fa.r;
     {
@@ -117,6 +117,9 @@ __global__ void __launch_bounds__(BLOCK, (MORT_MIN_WAVES * BLOCK + 767) / 768 > 
     V3 final_value = mk(0, 0, 0);
     unsigned long long tot_segments = 0, tot_draws = 0;
     StackEntry stack_deep[MORT_MAX_BOUNCE_LIMIT]; /* private overflow, touched only by paths deeper than the LDS part */
+    /* bit i set: bounce level i is a dielectric scatter, whose entry (k = (1,1,1), 1/pdf = 1) unwinds as
+     * final = 0 + 1*((1,1,1)*final) = 0 + final exactly -- such levels are neither stored nor loaded */
+    unsigned long long ident_mask = 0ull;
     float4 *stack_lds = (float4 *)(lds + fa.off_stack);
     const int DL = fa.stack_lds_depth;
 #ifdef MORT_PROFILE_STATES
@@ -224,6 +227,7 @@ __global__ void __launch_bounds__(BLOCK, (MORT_MIN_WAVES * BLOCK + 767) / 768 > 
                                 direction = refract(unit_direction, normal, refraction_ratio);
                             ray.o = p; ray.d = direction;
                             e.kx = 1.0f; e.ky = 1.0f; e.kz = 1.0f; e.rp = 1.0f;
+                            ident_mask |= (1ull << iter);
                         } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
                             const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
                             const DLambert m = lamb ? lambert[midx] : isotropic[midx];
@@ -277,8 +281,10 @@ __global__ void __launch_bounds__(BLOCK, (MORT_MIN_WAVES * BLOCK + 767) / 768 > 
                             kind = K_FINISH;
                         }
                         if (kind == K_SHADE) {
-                            if (iter < DL) { float4 e4; e4.x = e.kx; e4.y = e.ky; e4.z = e.kz; e4.w = e.rp; stack_lds[iter * BLOCK + threadIdx.x] = e4; }
-                            else stack_deep[iter] = e;
+                            if (!((ident_mask >> iter) & 1ull)) {
+                                if (iter < DL) { float4 e4; e4.x = e.kx; e4.y = e.ky; e4.z = e.kz; e4.w = e.rp; stack_lds[iter * BLOCK + threadIdx.x] = e4; }
+                                else stack_deep[iter] = e;
+                            }
                             iter++;
                             if (iter >= a.bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
                         }
@@ -288,12 +294,14 @@ __global__ void __launch_bounds__(BLOCK, (MORT_MIN_WAVES * BLOCK + 767) / 768 > 
                 if (kind == K_FINISH) { /* unwind + accumulate (camera.cuh:165-173,190) */
                     while (iter > 0) {
                         iter--;
+                        if ((ident_mask >> iter) & 1ull) { final_value = vadd(mk(0, 0, 0), final_value); continue; }
                         StackEntry e;
                         if (iter < DL) { const float4 e4 = stack_lds[iter * BLOCK + threadIdx.x]; e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w; }
                         else e = stack_deep[iter];
                         const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
                         final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
                     }
+                    ident_mask = 0ull;
                     pixel_color = vadd(pixel_color, final_value);
                     s++;
                     s_i++;
@@ -309,7 +317,7 @@ __global__ void __launch_bounds__(BLOCK, (MORT_MIN_WAVES * BLOCK + 767) / 768 > 
                             const int lyl = lofs / a.width, xl = lofs - lyl * a.width;
                             atomicAdd(&fa.tile_cost[(lyl >> 3) * fa.tiles_x + (xl >> 3)], segments);
                         }
-                        if (!fa.probe) {
+                        if (!PROBE) {
                             if (a.accum) { a.accum[3 * lofs] = c.x; a.accum[3 * lofs + 1] = c.y; a.accum[3 * lofs + 2] = c.z; }
                             float g[3] = {mort_sqrtf(c.x), mort_sqrtf(c.y), mort_sqrtf(c.z)};
                             unsigned char b[3];

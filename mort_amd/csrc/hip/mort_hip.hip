@@ -138,6 +138,7 @@ mega_kernel(const RenderArgs a) {
     }
 
     StackEntry stack[MORT_MAX_BOUNCE_LIMIT];
+    unsigned long long ident_mask = 0ull; /* levels whose entry is the identity (dielectric): not stored, see mega_bvh.h */
     V3 pixel_color = mk(0, 0, 0);
     const int spp = a.sqrt_spp * a.sqrt_spp;
     int s = 0, s_i = 0, s_j = 0;
@@ -191,8 +192,7 @@ mega_kernel(const RenderArgs a) {
                     else
                         direction = refract(unit_direction, rec.normal, refraction_ratio);
                     ray.o = rec.p; ray.d = direction;
-                    StackEntry e; e.kx = 1.0f; e.ky = 1.0f; e.kz = 1.0f; e.rp = 1.0f;
-                    stack[iter] = e;
+                    ident_mask |= (1ull << iter); /* entry (1,1,1), 1/pdf = 1 */
                     iter++;
                 } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
                     /* materials.cuh:38-44,182-188 + camera.cuh:115-145 */
@@ -243,10 +243,12 @@ mega_kernel(const RenderArgs a) {
         if (done) { /* unwind (camera.cuh:165-173) and accumulate (camera.cuh:190) */
             while (iter > 0) {
                 iter--;
+                if ((ident_mask >> iter) & 1ull) { final_value = vadd(mk(0, 0, 0), final_value); continue; }
                 const StackEntry e = stack[iter];
                 const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
                 final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
             }
+            ident_mask = 0ull;
             pixel_color = vadd(pixel_color, final_value);
             s++;
             s_i++;
@@ -827,12 +829,12 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             FB = 256;
             for (int k = 0; k < 4; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; }
         }
-        void (*kern)(const FastArgs) = nullptr;
+        void (*kern)(const FastArgs) = nullptr, (*kern_probe)(const FastArgs) = nullptr;
         switch (FB) {
-        case 768: kern = mega_bvh_kernel<768, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>; break;
-        case 512: kern = mega_bvh_kernel<512, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>; break;
-        case 384: kern = mega_bvh_kernel<384, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>; break;
-        default: FB = 256; kern = mega_bvh_kernel<256, MORT_TH_S, MORT_TH_L, MORT_T_KEEP>; break;
+        case 768: kern = mega_bvh_kernel<768, false>; kern_probe = mega_bvh_kernel<768, true>; break;
+        case 512: kern = mega_bvh_kernel<512, false>; kern_probe = mega_bvh_kernel<512, true>; break;
+        case 384: kern = mega_bvh_kernel<384, false>; kern_probe = mega_bvh_kernel<384, true>; break;
+        default: FB = 256; kern = mega_bvh_kernel<256, false>; kern_probe = mega_bvh_kernel<256, true>; break;
         }
         /* scheduling thresholds: batch for throughput when every lane has several pixels queued behind it, react fast
          * (small batches) when a rank owns about one pixel per lane and the frame is bound by its longest pixel chain */
@@ -886,8 +888,9 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
                 FastArgs pa = fa;
                 pa.r.states = c->d_probe_states; pa.r.sqrt_spp = 1; pa.r.recip_sqrt_spp = 1.0f; pa.r.pixel_samples_scale = 1.0f;
                 pa.r.accum = nullptr; pa.r.seg_px = nullptr;
-                pa.tile_order = nullptr; pa.tile_cost = c->d_tile_cost; pa.probe = 1;
-                hipLaunchKernelGGL(kern, dim3(grid), dim3(FB), lds_bytes, s, pa);
+                pa.tile_order = nullptr; pa.tile_cost = c->d_tile_cost;
+                HIPCHK(c, hipFuncSetAttribute((const void *)kern_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+                hipLaunchKernelGGL(kern_probe, dim3(grid), dim3(FB), lds_bytes, s, pa);
                 HIPCHK(c, hipGetLastError());
                 HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
                 c->cost_key = key;
@@ -901,7 +904,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             std::stable_sort(c->h_order.begin(), c->h_order.end(), [cost](unsigned x, unsigned y) { return cost[x] > cost[y]; });
             HIPCHK(c, hipMemcpyAsync(c->d_tile_order, c->h_order.data(), (size_t)tiles * sizeof(unsigned), hipMemcpyHostToDevice, s));
             HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
-            fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost; fa.probe = 0;
+            fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost;
             if (stats) HIPCHK(c, hipEventRecord(c->ev0, s)); /* time the frame itself; ordering upkeep is reported by wall-clock benches */
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FB), lds_bytes, s, fa);
