@@ -70,6 +70,7 @@ typedef struct mort_stats {
     int scene_in_lds;        /* 1 if the kernel staged the scene in LDS */
     int local_rows;          /* rows owned under the partition */
     int kernel_vgprs, kernel_lds_bytes; /* launch facts, for reports */
+    uint64_t reference_walks; /* BVH megakernel: segments re-traced with the reference's own walk */
 } mort_stats;
 
 const char *mort_hip_strerror(int status);

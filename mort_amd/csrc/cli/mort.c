@@ -97,11 +97,11 @@ int main(int argc, char **argv) {
     int eff = mort_camera_effective_spp(&cam);
     printf("{\"scene\": %d, \"width\": %d, \"height\": %d, \"spp_nominal\": %d, \"spp_effective\": %d, \"depth\": %d, "
            "\"seconds\": %.6f, \"msamples_per_s\": %.3f, \"segments\": %llu, \"segments_per_s\": %.4g, "
-           "\"algorithmic_hbm_bytes\": %llu, \"hbm_GBps\": %.4g, \"hbm_frac_of_8TBps\": %.3g}\n",
+           "\"algorithmic_hbm_bytes\": %llu, \"hbm_GBps\": %.4g, \"hbm_frac_of_8TBps\": %.3g, \"reference_walks\": %llu}\n",
            scene, W, H, cam.samples_per_pixel, eff, cam.bounce_limit, stats.seconds,
            (double)npx * eff / stats.seconds / 1e6, (unsigned long long)stats.segments, stats.segments / stats.seconds,
            (unsigned long long)stats.algorithmic_hbm_bytes, stats.algorithmic_hbm_bytes / stats.seconds / 1e9,
-           stats.algorithmic_hbm_bytes / stats.seconds / 8e12);
+           stats.algorithmic_hbm_bytes / stats.seconds / 8e12, (unsigned long long)stats.reference_walks);
     if (out && mort_write_ppm(out, rgba, W, H) != 0) { fprintf(stderr, "cannot write %s\n", out); return EXIT_FAILURE; }
     if (dump) {
         FILE *f = fopen(dump, "wb");

@@ -48,6 +48,20 @@ struct __attribute__((aligned(16))) DBvhNode {
     uint32_t prims; /* leaf: primA | primB << 16; prim = kind << 15 | index (kind 0 sphere, 1 quad) */
 };
 
+/* Node of this build's OWN tree over the reference's leaf nodes (mega_bvh.h; scene_compile.h build_own_tree): the
+ * boxes of its two children, 64 B = four ds_read_b128.  A child reference is a node index, or 0x8000 | leaf index
+ * (leaf records are DBvhNode: the reference leaf node's box, bit for bit, and its one or two spheres).
+ * e0/e1: anomaly margin of the child in world units (largest leaf-box diagonal below it + 8e-3 x its own diagonal). */
+struct __attribute__((aligned(16))) DNode2 {
+    float x0min, x0max, y0min, y0max;
+    float z0min, z0max, x1min, x1max;
+    float y1min, y1max, z1min, z1max;
+    uint32_t child0, child1;
+    float e0, e1;
+};
+#define MORT_OWN_STACK 16 /* pending far children per lane kept in LDS; deeper walks use the reference walk */
+#define MORT_OWN_MAX_DEPTH 15
+
 enum { XF_TRANSLATE = 0, XF_ROTATE_Y = 1 };
 struct __attribute__((aligned(16))) DXform { /* 16 B */
     int kind;

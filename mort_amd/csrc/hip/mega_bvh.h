@@ -24,11 +24,20 @@
  *    order (one atomicAdd per wave per refill, lanes ranked by mbcnt), so the
  *    chip stays full until the pool is empty.
  *
- *  - aabb::hit (aabb.cuh:37-59) per node: the fp64 reciprocals are per ray;
- *    `if (t0 > t_min) t_min = t0` on a float t_min is max(t_min, (float)t0)
- *    (rounding is monotonic; a NaN t0 leaves t_min unchanged, as v_max_f32
- *    does), the per-axis early-outs are equivalent to one final compare, and
- *    the near/far swap is a select on the sign of 1/dir.
+ *  - Own tree, near child first.  The reference walks its median-split tree left-first (objects.cuh:664-723), 41
+ *    box tests per segment in Scene 1.  bvh_node::hit returns the closest accepted sphere hit; WHICH one that is
+ *    depends on the walk only through the leaf nodes it refuses to enter.  So this kernel walks its own SAH tree
+ *    over the reference's leaf nodes (13 two-box steps per segment), and proves per ray that the reference's walk
+ *    would have returned the same sphere -- or else repeats the ray with the reference's walk:
+ *      * leaf records keep the reference leaf box bit for bit, inner boxes are exact unions, so aabb::hit
+ *        (aabb.cuh:37-59) passing on a leaf implies it passes on every box above it, in either tree (rounding is
+ *        monotonic); the fp32 prune below is conservative against aabb::hit (error band tau);
+ *      * a box is skipped "because of closest_so_far" only if it is entered later than closest_so_far by more
+ *        than the length of the longest leaf box below it (+ 0.8 %): this cannot hide a sphere hit that lies
+ *        BEFORE the entry into its own leaf box (the only kind whose acceptance depends on visiting order);
+ *      * the winner (minimum t over all sphere hits seen, ties flagged) is accepted iff aabb::hit of its leaf
+ *        box passes with t_max = t, evaluated exactly as the reference does (slab_check).  If not, or on a tie,
+ *        or for rays whose reciprocal direction is not an ordinary float, the reference's own walk is run.
  *
  *  - Hit record rebuilt only for the winner; sphere uv (acosf/atan2f) only when
  *    the material's texture reads it.
@@ -42,8 +51,9 @@ struct FastArgs {
     RenderArgs r;
     const unsigned char *hot_src; /* device copy of the hot blob */
     uint32_t hot_bytes;
-    uint32_t off_nodes, off_spheres, off_lambert, off_metal, off_diel, off_dlight, off_iso, off_solid, off_checker;
-    int node_first, node_count;
+    uint32_t off_nodes2, off_leaves, off_spheres, off_lambert, off_metal, off_diel, off_dlight, off_iso, off_solid, off_checker;
+    uint32_t off_tstack;  /* LDS offset of the per-lane traversal stacks: [MORT_OWN_STACK][thread] u16 */
+    int node_first, node_count; /* the reference's threaded nodes in r.sc.nodes (HBM): fallback walk only */
     unsigned int *next_q; /* work counter, zeroed before launch */
     int tiles_x, tiles_total;
     uint32_t off_stack;   /* LDS offset of the per-lane bounce stacks: [depth][thread] float4 */
@@ -55,6 +65,47 @@ struct FastArgs {
 };
 
 enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
+enum { FL_TIE = 1, FL_REF = 2 };
+
+DEV bool own_inv_ok(float v) { const float a = mort_fabsf(v); return a > 1e-15f && a < 1e15f; } /* !(NaN) too */
+/* per-ray constants of the own-tree box test: p = b * inv - o * inv */
+struct OwnRay { float ix, iy, iz, mx, my, mz, band, invlen; };
+
+/* true = skip the box.  te: entry distance (>= t_min = 0.001).
+ * Conservative against aabb::hit at any t_max > closest: |p - reference's (b - o) * inv| <= 2^-21 |p| + 2^-24 |o * inv|,
+ * tau = 2^-20 max(|te|, |tx|) + 2^-21 max |o * inv|. */
+DEV bool own_prune(float xmin, float xmax, float ymin, float ymax, float zmin, float zmax, float e, const OwnRay &r, float closest, float &te_out) {
+    const float px0 = __builtin_fmaf(xmin, r.ix, -r.mx), px1 = __builtin_fmaf(xmax, r.ix, -r.mx);
+    const float py0 = __builtin_fmaf(ymin, r.iy, -r.my), py1 = __builtin_fmaf(ymax, r.iy, -r.my);
+    const float pz0 = __builtin_fmaf(zmin, r.iz, -r.mz), pz1 = __builtin_fmaf(zmax, r.iz, -r.mz);
+    const float te = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(px0, px1), __builtin_fminf(py0, py1)),
+                                     __builtin_fmaxf(__builtin_fminf(pz0, pz1), 0.001f));
+    const float tx = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(px0, px1), __builtin_fmaxf(py0, py1)), __builtin_fmaxf(pz0, pz1));
+    const float tau = __builtin_fmaf(__builtin_fmaxf(mort_fabsf(te), mort_fabsf(tx)), 9.5367431640625e-07f, r.band);
+    const float key = __builtin_fmaf(te, 0.992f, -__builtin_fmaf(e, r.invlen, tau));
+    te_out = te;
+    return (tx - te < -tau) || (key > closest);
+}
+
+/* aabb::hit (aabb.cuh:37-59) with t_min = 0.001, t_max = closest: the reference's boolean (see slab_hit), the fp64
+ * reciprocals computed only for the rare ray inside the fp32 error band.  Caller: the ray has ordinary reciprocals. */
+DEV bool slab_check(const DBvhNode &nd, const Ray &ray, const OwnRay &r, float closest) {
+    /* r.i* = fl32(1 / d): within one ulp of slab_hit's fl32(1.0 / (double)d), inside its error budget (4u of 16u) */
+    const float px0 = (nd.xmin - ray.o.x) * r.ix, px1 = (nd.xmax - ray.o.x) * r.ix;
+    const float py0 = (nd.ymin - ray.o.y) * r.iy, py1 = (nd.ymax - ray.o.y) * r.iy;
+    const float pz0 = (nd.zmin - ray.o.z) * r.iz, pz1 = (nd.zmax - ray.o.z) * r.iz;
+    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(px0, px1), __builtin_fminf(py0, py1)),
+                                        __builtin_fmaxf(__builtin_fminf(pz0, pz1), 0.001f));
+    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(px0, px1), __builtin_fmaxf(py0, py1)),
+                                        __builtin_fminf(__builtin_fmaxf(pz0, pz1), closest));
+    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mort_fabsf(px0), mort_fabsf(px1)), __builtin_fmaxf(mort_fabsf(py0), mort_fabsf(py1))),
+                                    __builtin_fmaxf(mort_fabsf(pz0), mort_fabsf(pz1)));
+    const float gap = t_max - t_min;
+    const bool decided = (mort_fabsf(gap) > m * 9.5367431640625e-07f) && (m < 1e30f) && (m > 1e-30f);
+    bool hit = gap > 0;
+    if (!decided) hit = slab_exact(nd, ray.o.x, ray.o.y, ray.o.z, 1.0 / (double)ray.d.x, 1.0 / (double)ray.d.y, 1.0 / (double)ray.d.z, closest);
+    return hit;
+}
 enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 
 #ifndef MORT_TH_S
@@ -86,7 +137,9 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
     }
     __syncthreads();
-    const DBvhNode *nodes = (const DBvhNode *)(lds + fa.off_nodes);
+    const DNode2 *nodes2 = (const DNode2 *)(lds + fa.off_nodes2);
+    const DBvhNode *leaves = (const DBvhNode *)(lds + fa.off_leaves);
+    unsigned short *tstack = (unsigned short *)(lds + fa.off_tstack) + threadIdx.x; /* [level * BLOCK] */
     const DSphere *spheres = (const DSphere *)(lds + fa.off_spheres);
     const DLambert *lambert = (const DLambert *)(lds + fa.off_lambert);
     const DMetal *metal = (const DMetal *)(lds + fa.off_metal);
@@ -110,10 +163,12 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
     uint32_t segments = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.tm = 0;
     float ray_time0 = 0;
-    SlabRay sr = slab_ray(0, 0, 0, 0, 0, 1);
+    OwnRay orr; orr.ix = orr.iy = orr.iz = 1; orr.mx = orr.my = orr.mz = 0; orr.band = 0; orr.invlen = 1;
     float ray_a = 1, closest = 0;
-    int best = -1, node = 0;
-    uint32_t leaf_prims = 0;
+    int best = -1;         /* sphere | leaf << 16 of the closest hit so far */
+    uint32_t node = 0;     /* T: own-tree node; L: leaf record */
+    int sp = 0, flags = 0; /* pending far children; FL_TIE / FL_REF */
+    unsigned fallbacks = 0;
     V3 final_value = mk(0, 0, 0);
     unsigned long long tot_segments = 0, tot_draws = 0;
     StackEntry stack_deep[MORT_MAX_BOUNCE_LIMIT]; /* private overflow, touched only by paths deeper than the LDS part */
@@ -152,42 +207,57 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
         PROFC(3);
 
         if (pick == ST_T) {
-            /* ---- box steps (aabb::hit + one move of the threaded walk) ---- */
+            /* ---- own-tree steps: both child boxes of one node, near child next, far child pushed ---- */
             int keep;
             do {
                 PROF(0, __popcll(__ballot(state == ST_T)));
                 if (state == ST_T) {
-                    const DBvhNode nd = nodes[node];
-                    const bool miss = !slab_hit(nd, sr, closest); /* aabb::hit (aabb.cuh:37-59), fp32-decided when provable */
-                    const int skip = (int)(nd.skip & 0x7fffffffu);
-                    if (miss) {
-                        node = skip;
-                    } else if (nd.skip >> 31) {
-                        leaf_prims = nd.prims;
-                        node = skip;
-                        state = ST_L;
-                    } else {
-                        node = node + 1;
-                    }
-                    if (state == ST_T && node >= node_end) { state = ST_S; kind = K_SHADE; }
+                    const float4 *np = (const float4 *)(nodes2 + node);
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    float te0, te1;
+                    const bool m0 = own_prune(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.z, orr, closest, te0);
+                    const bool m1 = own_prune(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.w, orr, closest, te1);
+                    const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                    uint32_t next = 0;
+                    bool have = true;
+                    if (!m0 && !m1) {
+                        const bool first0 = te0 <= te1;
+                        next = first0 ? c0 : c1;
+                        tstack[sp * BLOCK] = (unsigned short)(first0 ? c1 : c0);
+                        sp++;
+                    } else if (!m0) next = c0;
+                    else if (!m1) next = c1;
+                    else if (sp > 0) { sp--; next = tstack[sp * BLOCK]; }
+                    else have = false;
+                    if (!have) { state = ST_S; kind = K_SHADE; }
+                    else { node = next & 0x7fffu; if (next & 0x8000u) state = ST_L; }
                 }
                 keep = __popcll(__ballot(state == ST_T));
             } while (keep >= t_keep);
             PROFC(0);
         } else if (pick == ST_L) {
-            /* ---- leaf: sphere::hit on one or two spheres (objects.cuh:60-77,690-692) ---- */
+            /* ---- leaf: sphere::hit on the one or two spheres of a reference leaf node (objects.cuh:60-77,690-692) ---- */
             PROF(1, nL);
             if (state == ST_L) {
+                const uint32_t leaf_prims = leaves[node].prims;
                 const uint32_t pa = leaf_prims & 0x7fffu, pb = (leaf_prims >> 16) & 0x7fffu;
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const uint32_t p = k ? pb : pa;
                     if (k == 1 && pb == pa) break;
-                    const DSphere sp = spheres[p];
+                    const DSphere sp_ = spheres[p];
                     float t;
-                    if (sphere_hit_t(sp, ray, ray_a, 0.001f, closest, t)) { closest = t; best = (int)p; }
+                    if (sphere_hit_t(sp_, ray, ray_a, 0.001f, closest, t)) {
+                        if (t == closest && best >= 0) flags |= FL_TIE; /* the reference keeps whichever it visits last */
+                        closest = t; best = (int)(p | (node << 16));
+                    }
                 }
-                if (node >= node_end) { state = ST_S; kind = K_SHADE; } else state = ST_T;
+                if (sp > 0) {
+                    sp--;
+                    const uint32_t next = tstack[sp * BLOCK];
+                    node = next & 0x7fffu;
+                    state = (next & 0x8000u) ? ST_L : ST_T;
+                } else { state = ST_S; kind = K_SHADE; }
             }
             PROFC(1);
         } else {
@@ -196,6 +266,30 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
             PROFS0();
             if (state == ST_S) {
                 if (kind == K_SHADE) {
+                    /* is the winner what bvh_node::hit returns?  (header comment) */
+                    bool need_ref = flags != 0;
+                    if (!need_ref && best >= 0) need_ref = !slab_check(leaves[best >> 16], ray, orr, closest);
+                    if (need_ref) { /* the reference's walk (objects.cuh:664-723) over its own threaded nodes */
+                        fallbacks++;
+                        closest = __builtin_inff(); best = -1;
+                        const double dix = 1.0 / (double)ray.d.x, diy = 1.0 / (double)ray.d.y, diz = 1.0 / (double)ray.d.z;
+                        int n = node_first;
+                        while (n < node_end) {
+                            const DBvhNode nd = a.sc.nodes[n];
+                            const int skip = (int)(nd.skip & 0x7fffffffu);
+                            if (!slab_exact(nd, ray.o.x, ray.o.y, ray.o.z, dix, diy, diz, closest)) { n = skip; continue; }
+                            if (!(nd.skip >> 31)) { n = n + 1; continue; }
+                            const uint32_t pa = nd.prims & 0x7fffu, pb = (nd.prims >> 16) & 0x7fffu;
+                            for (int k = 0; k < 2; k++) {
+                                const uint32_t p = k ? pb : pa;
+                                if (k == 1 && pb == pa) break;
+                                float t;
+                                if (sphere_hit_t(spheres[p], ray, ray_a, 0.001f, closest, t)) { closest = t; best = (int)p; }
+                            }
+                            n = skip;
+                        }
+                    }
+                    if (best >= 0) best &= 0x7fff;
                     if (best < 0) { /* camera.cuh:154-158 */
                         final_value = a.background;
                         kind = K_FINISH;
@@ -386,13 +480,19 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         if (a.bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
                     }
                     if (kind == K_SHADE) { /* start world::hit for the new ray */
-                        sr = slab_ray(ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
                         ray_a = vlen2(ray.d);
+                        orr.ix = 1.0f / ray.d.x; orr.iy = 1.0f / ray.d.y; orr.iz = 1.0f / ray.d.z;
+                        orr.mx = ray.o.x * orr.ix; orr.my = ray.o.y * orr.iy; orr.mz = ray.o.z * orr.iz;
+                        const float mm = __builtin_fmaxf(__builtin_fmaxf(mort_fabsf(orr.mx), mort_fabsf(orr.my)), mort_fabsf(orr.mz));
+                        orr.band = mm * 4.76837158203125e-07f; /* 2^-21 */
+                        orr.invlen = 1.01f / mort_sqrtf(ray_a);
+                        const bool ordinary = own_inv_ok(orr.ix) && own_inv_ok(orr.iy) && own_inv_ok(orr.iz) && (mm < 1e30f);
                         closest = __builtin_inff();
                         best = -1;
-                        node = node_first;
+                        node = 0; sp = 0;
+                        flags = ordinary ? 0 : FL_REF;
                         segments++;
-                        state = (node < node_end) ? ST_T : ST_S;
+                        state = ordinary ? ST_T : ST_S;
                     }
                     /* kind == K_FINISH here (bounce_limit 0 or spp 0): stays in ST_S for the next S step */
                 }
@@ -402,13 +502,16 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
         }
     }
     /* per-wave totals */
+    unsigned long long fb_total = fallbacks;
     for (int off = 32; off > 0; off >>= 1) {
         tot_segments += __shfl_down(tot_segments, off);
         tot_draws += __shfl_down(tot_draws, off);
+        fb_total += __shfl_down(fb_total, off);
     }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&a.counters[0], tot_segments);
         atomicAdd(&a.counters[1], tot_draws);
+        if (fb_total) atomicAdd(&a.counters[3], fb_total);
 #ifdef MORT_PROFILE_STATES
         for (int k = 0; k < 6; k++) atomicAdd(&a.counters[4 + k], prof[k]);
         for (int k = 0; k < 4; k++) atomicAdd(&a.counters[10 + k], profc[k]);

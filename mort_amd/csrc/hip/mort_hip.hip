@@ -361,6 +361,12 @@ struct mort_ctx {
     /* fast (BVH-in-LDS) kernel: offsets of the tables inside the hot blob */
     uint32_t off_nodes = 0, off_spheres = 0, off_lambert = 0, off_metal = 0, off_diel = 0, off_dlight = 0, off_iso = 0,
              off_solid = 0, off_checker = 0, hot_bytes = 0;
+    bool wave_ok = false; /* wavefront mode: one BVH over spheres as the whole world, hot blob fits LDS */
+    /* BVH megakernel: its own LDS image (own tree, reference leaf records, spheres, material / texture tables) */
+    void *d_fast = nullptr;
+    uint32_t f_nodes2 = 0, f_leaves = 0, f_spheres = 0, f_lambert = 0, f_metal = 0, f_diel = 0, f_dlight = 0, f_iso = 0,
+             f_solid = 0, f_checker = 0, fast_bytes = 0;
+    int own_nodes = 0, own_leaves = 0;
     bool fast_ok = false;
     int num_cus = 256;
     /* pixel-tile ordering of the BVH megakernel: most expensive tiles first (cost = segments of the previous
@@ -472,7 +478,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    hipFree(c->d_scene); hipFree(c->d_states); hipFree(c->d_seqmats);
+    hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
     hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states);
     if (c->h_live) hipHostFree(c->h_live);
@@ -595,8 +601,26 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     c->off_nodes = (uint32_t)o_nodes; c->off_spheres = (uint32_t)o_sph; c->off_lambert = (uint32_t)o_lamb;
     c->off_metal = (uint32_t)o_metal; c->off_diel = (uint32_t)o_diel; c->off_dlight = (uint32_t)o_dl; c->off_iso = (uint32_t)o_iso;
     c->off_solid = (uint32_t)o_solid; c->off_checker = (uint32_t)o_chk; c->hot_bytes = (uint32_t)hot_bytes;
-    /* the LDS state-machine kernel handles: one BVH over spheres as the whole world */
-    c->fast_ok = (o.items.size() == 1 && o.items[0].kind == ITEM_BVH && o.quads.empty() && hot_bytes <= 64 * 1024);
+    /* the LDS kernels handle: one BVH over spheres as the whole world */
+    c->wave_ok = (o.items.size() == 1 && o.items[0].kind == ITEM_BVH && o.quads.empty() && hot_bytes <= 64 * 1024);
+    c->fast_ok = false;
+    if (c->d_fast) { hipFree(c->d_fast); c->d_fast = nullptr; }
+    if (c->wave_ok && !o.own_nodes.empty()) {
+        std::vector<unsigned char> fb;
+        c->f_nodes2 = (uint32_t)place(fb, o.own_nodes); c->f_leaves = (uint32_t)place(fb, o.own_leaves);
+        c->f_spheres = (uint32_t)place(fb, o.spheres);
+        c->f_lambert = (uint32_t)place(fb, o.lambert); c->f_metal = (uint32_t)place(fb, o.metal); c->f_diel = (uint32_t)place(fb, o.dielectric);
+        c->f_dlight = (uint32_t)place(fb, o.dlight); c->f_iso = (uint32_t)place(fb, o.isotropic);
+        c->f_solid = (uint32_t)place(fb, o.solid); c->f_checker = (uint32_t)place(fb, o.checker);
+        fb.resize((fb.size() + 15) & ~(size_t)15, 0);
+        if (fb.size() <= 72 * 1024) {
+            HIPCHK(c, hipMalloc(&c->d_fast, fb.size()));
+            HIPCHK(c, hipMemcpy(c->d_fast, fb.data(), fb.size(), hipMemcpyHostToDevice));
+            c->fast_bytes = (uint32_t)fb.size();
+            c->own_nodes = (int)o.own_nodes.size(); c->own_leaves = (int)o.own_leaves.size();
+            c->fast_ok = true;
+        }
+    }
     c->have_world = true;
     return MORT_OK;
 }
@@ -800,7 +824,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     const void *fast_kernel_used = nullptr;
     if (mode == MORT_MODE_WAVE) {
         /* the wavefront pipeline covers: one BVH of spheres as the world, no light object */
-        if (!(c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1))
+        if (!(c->wave_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1))
             return MORT_ERR_UNSUPPORTED;
     }
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
@@ -812,10 +836,10 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         FastArgs fa;
         std::memset(&fa, 0, sizeof fa);
         fa.r = a;
-        fa.hot_src = (const unsigned char *)c->d_scene; fa.hot_bytes = c->hot_bytes;
-        fa.off_nodes = c->off_nodes; fa.off_spheres = c->off_spheres; fa.off_lambert = c->off_lambert; fa.off_metal = c->off_metal;
-        fa.off_diel = c->off_diel; fa.off_dlight = c->off_dlight; fa.off_iso = c->off_iso; fa.off_solid = c->off_solid; fa.off_checker = c->off_checker;
-        fa.node_first = 0; fa.node_count = c->sc.n_nodes;
+        fa.hot_src = (const unsigned char *)c->d_fast; fa.hot_bytes = c->fast_bytes;
+        fa.off_nodes2 = c->f_nodes2; fa.off_leaves = c->f_leaves; fa.off_spheres = c->f_spheres; fa.off_lambert = c->f_lambert; fa.off_metal = c->f_metal;
+        fa.off_diel = c->f_diel; fa.off_dlight = c->f_dlight; fa.off_iso = c->f_iso; fa.off_solid = c->f_solid; fa.off_checker = c->f_checker;
+        fa.node_first = 0; fa.node_count = c->sc.n_nodes; /* the reference's threaded nodes (HBM): fallback walk */
         fa.next_q = (unsigned int *)(c->d_counters + 2);
         fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
         /* workgroup size: the largest of {768, 512, 384, 256} that still gives every CU a workgroup
@@ -847,7 +871,9 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             if (th) { int s_ = 0, l_ = 0, k_ = 0; if (std::sscanf(th, "%d,%d,%d", &s_, &l_, &k_) == 3) { fa.th_s = s_; fa.th_l = l_; fa.t_keep = k_; } }
         }
         /* LDS: hot blob + as many bounce-stack levels per lane as fit next to it (768 threads: one workgroup per CU) */
-        const uint32_t stack_off = (c->hot_bytes + 15u) & ~15u;
+        const uint32_t tstack_off = (c->fast_bytes + 15u) & ~15u; /* traversal stacks: [MORT_OWN_STACK][thread] u16 */
+        const uint32_t stack_off = tstack_off + (uint32_t)MORT_OWN_STACK * (uint32_t)FB * 2u;
+        fa.off_tstack = tstack_off;
         const int groups_per_cu = 768 / FB; /* keep 12 waves per CU */
         int dl = (int)(((160u * 1024u - 256u) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
         if (dl > 12) dl = 12;
@@ -948,6 +974,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         stats->seconds = ms * 1e-3;
         stats->segments = cnt[0];
         stats->rng_draws = cnt[1];
+        stats->reference_walks = (use_fast && mode != MORT_MODE_WAVE) ? cnt[3] : 0;
         stats->pixels = (uint64_t)W * (uint64_t)a.local_rows;
         stats->eff_samples = stats->pixels * (uint64_t)(cam->sqrt_spp * cam->sqrt_spp);
         stats->algorithmic_hbm_bytes = stats->pixels * (uint64_t)(100 + (d_accum ? 12 : 0));

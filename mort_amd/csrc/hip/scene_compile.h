@@ -42,6 +42,10 @@ struct Compiled {
     int list_first[MORT_NUM_HITTABLE_LIST], list_count[MORT_NUM_HITTABLE_LIST];
     int status = MORT_OK;
     bool inverted_box = false; /* some BVH node has min > max on an axis */
+    /* this build's own tree over the leaf nodes of items[0] (BVH megakernel); empty when not applicable */
+    std::vector<DNode2> own_nodes;
+    std::vector<DBvhNode> own_leaves;
+    int own_depth = 0;
 };
 
 static inline DSphere to_dsphere(const mort_sphere &s) {
@@ -297,6 +301,101 @@ struct Compiler {
         }
     }
 
+    /* ---- this build's own tree over the LEAF NODES of a reference BVH (mega_bvh.h walks it near-child-first).
+     * Leaves keep the reference leaf node's box bit for bit; inner boxes are exact float unions of them, so the
+     * reference's box test of a leaf implies the same test of every box above it (rounding is monotonic).  Split by
+     * the surface-area heuristic (exhaustive sweep; a few hundred leaves), depth-limited so the device stack of
+     * pending far children (MORT_OWN_STACK) can never overflow. ---- */
+    struct OwnBuild {
+        std::vector<Box> lb;       /* leaf boxes */
+        std::vector<double> ldiag; /* leaf box diagonals */
+        std::vector<DNode2> *nodes;
+        int max_depth_seen = 0;
+    };
+    static Box box_union(Box a, const Box &b) {
+        for (int k = 0; k < 3; k++) { a.lo[k] = std::fmin(a.lo[k], b.lo[k]); a.hi[k] = std::fmax(a.hi[k], b.hi[k]); }
+        return a;
+    }
+    static double box_area(const Box &b) {
+        const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
+        return 2.0 * (x * y + y * z + z * x);
+    }
+    static double box_diag(const Box &b) {
+        const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
+        return std::sqrt(x * x + y * y + z * z);
+    }
+    /* returns the child reference of the subtree over ids[lo,hi); fills box / margin of that subtree */
+    uint32_t own_emit(OwnBuild &ob, std::vector<int> &ids, int lo, int hi, int depth, Box &box_out, float &e_out) {
+        const int n = hi - lo;
+        Box u = ob.lb[ids[lo]];
+        double ml = ob.ldiag[ids[lo]];
+        for (int i = lo + 1; i < hi; i++) { u = box_union(u, ob.lb[ids[i]]); ml = std::fmax(ml, ob.ldiag[ids[i]]); }
+        box_out = u;
+        e_out = std::nextafter((float)(ml * 1.001 + 8e-3 * box_diag(u)), INFINITY);
+        if (n == 1) return 0x8000u | (uint32_t)ids[lo];
+        if (depth > ob.max_depth_seen) ob.max_depth_seen = depth;
+        /* levels left below this node, this one included: both halves must fit in 2^(left-1) leaves */
+        const int left = MORT_OWN_MAX_DEPTH - depth;
+        const long long cap = left >= 2 ? (1ll << (left - 1 < 30 ? left - 1 : 30)) : 1;
+        double best = 1e300; int bax = 0, bsplit = n / 2;
+        std::vector<int> tmp(n);
+        std::vector<double> ra(n);
+        for (int ax = 0; ax < 3; ax++) {
+            std::copy(ids.begin() + lo, ids.begin() + hi, tmp.begin());
+            std::stable_sort(tmp.begin(), tmp.end(), [&](int a, int b) { return ob.lb[a].lo[ax] + ob.lb[a].hi[ax] < ob.lb[b].lo[ax] + ob.lb[b].hi[ax]; });
+            Box r = ob.lb[tmp[n - 1]]; ra[n - 1] = box_area(r);
+            for (int i = n - 2; i >= 0; i--) { r = box_union(r, ob.lb[tmp[i]]); ra[i] = box_area(r); }
+            Box l = ob.lb[tmp[0]];
+            for (int i = 1; i < n; i++) {
+                if (i <= cap && n - i <= cap) {
+                    const double c = box_area(l) * i + ra[i] * (n - i);
+                    if (c < best) { best = c; bax = ax; bsplit = i; }
+                }
+                l = box_union(l, ob.lb[tmp[i]]);
+            }
+        }
+        std::stable_sort(ids.begin() + lo, ids.begin() + hi, [&](int a, int b) { return ob.lb[a].lo[bax] + ob.lb[a].hi[bax] < ob.lb[b].lo[bax] + ob.lb[b].hi[bax]; });
+        const size_t me = ob.nodes->size();
+        ob.nodes->push_back(DNode2{});
+        Box b0, b1; float e0, e1;
+        const uint32_t c0 = own_emit(ob, ids, lo, lo + bsplit, depth + 1, b0, e0);
+        const uint32_t c1 = own_emit(ob, ids, lo + bsplit, hi, depth + 1, b1, e1);
+        DNode2 nd;
+        nd.x0min = b0.lo[0]; nd.x0max = b0.hi[0]; nd.y0min = b0.lo[1]; nd.y0max = b0.hi[1]; nd.z0min = b0.lo[2]; nd.z0max = b0.hi[2];
+        nd.x1min = b1.lo[0]; nd.x1max = b1.hi[0]; nd.y1min = b1.lo[1]; nd.y1max = b1.hi[1]; nd.z1min = b1.lo[2]; nd.z1max = b1.hi[2];
+        nd.child0 = c0; nd.child1 = c1; nd.e0 = e0; nd.e1 = e1;
+        (*ob.nodes)[me] = nd;
+        return (uint32_t)me;
+    }
+    void build_own_tree() {
+        out.own_nodes.clear(); out.own_leaves.clear(); out.own_depth = 0;
+        if (out.items.size() != 1 || out.items[0].kind != ITEM_BVH || !out.quads.empty()) return;
+        const DItem &it = out.items[0];
+        OwnBuild ob;
+        ob.nodes = &out.own_nodes;
+        std::vector<DBvhNode> leaves;
+        for (int i = it.first; i < it.first + it.count; i++) {
+            const DBvhNode &nd = out.nodes[i];
+            if (!(nd.skip >> 31)) continue;
+            if ((nd.prims & 0x8000u) || ((nd.prims >> 16) & 0x8000u)) return; /* spheres only */
+            Box b;
+            b.lo[0] = nd.xmin; b.hi[0] = nd.xmax; b.lo[1] = nd.ymin; b.hi[1] = nd.ymax; b.lo[2] = nd.zmin; b.hi[2] = nd.zmax;
+            for (int k = 0; k < 3; k++) if (!std::isfinite(b.lo[k]) || !std::isfinite(b.hi[k]) || b.lo[k] > b.hi[k]) return;
+            ob.lb.push_back(b); ob.ldiag.push_back(box_diag(b));
+            leaves.push_back(nd);
+        }
+        const int n = (int)leaves.size();
+        if (n < 2 || n > 0x7fff) return;
+        std::vector<int> ids(n);
+        for (int i = 0; i < n; i++) ids[i] = i;
+        Box rb; float re;
+        const uint32_t root = own_emit(ob, ids, 0, n, 0, rb, re);
+        if (root != 0 || out.own_nodes.size() > 0x7fff || ob.max_depth_seen + 1 > MORT_OWN_MAX_DEPTH) { out.own_nodes.clear(); return; }
+        for (const DNode2 &nd : out.own_nodes) if (!std::isfinite(nd.e0) || !std::isfinite(nd.e1)) { out.own_nodes.clear(); return; }
+        out.own_leaves = leaves;
+        out.own_depth = ob.max_depth_seen + 1;
+    }
+
     static uint32_t tex_ref(int type, int idx) { return DREF(type & 0x7fff, idx & 0xffff); }
 
     DLambert tex_material(int tex_type, int tex_idx) {
@@ -334,6 +433,7 @@ struct Compiler {
         if (!std::getenv("MORT_NO_ACCEL")) { build_accels(out.items); build_accels(out.subitems); }
         else { for (DItem &it : out.items) { it.accel_first = 0; if (it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) it.medium = 0; }
                for (DItem &it : out.subitems) { it.accel_first = 0; if (it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) it.medium = 0; } }
+        build_own_tree();
         /* world-order copies for light sampling */
         for (int i = 0; i < o.num_spheres; i++) out.wspheres.push_back(to_dsphere(o.host_sphere[i]));
         for (int i = 0; i < o.num_quads; i++) out.wquads.push_back(to_dquad(o.host_quad[i]));

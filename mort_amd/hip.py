@@ -35,7 +35,7 @@ class Stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("segments", C.c_uint64), ("pixels", C.c_uint64),
                 ("eff_samples", C.c_uint64), ("rng_draws", C.c_uint64), ("algorithmic_hbm_bytes", C.c_uint64),
                 ("scene_in_lds", C.c_int), ("local_rows", C.c_int), ("kernel_vgprs", C.c_int),
-                ("kernel_lds_bytes", C.c_int)]
+                ("kernel_lds_bytes", C.c_int), ("reference_walks", C.c_uint64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
