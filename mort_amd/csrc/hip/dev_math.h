@@ -51,7 +51,10 @@ DEV float curand_uniform_f(Rng &s) {
     uint32_t x = xorwow_next(s);
     return (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
 }
-DEV float random_float(Rng &s) { return (float)(1.0 - (double)curand_uniform_f(s)); }           /* rng.cuh:17-23 */
+/* rng.cuh:17-23 computes (float)(1.0 - (double)u).  u >= 2^-33 has 24 significant bits, so 1 - u is exact in fp64
+ * unless u < 2^-29 (where both roundings give 1.0f); the fp32 subtraction rounds the same exact value once.
+ * Checked for all 2^32 generator outputs (tests/test_rng.py). */
+DEV float random_float(Rng &s) { return 1.0f - curand_uniform_f(s); }
 DEV float random_float_range(Rng &s, float mn, float mx) { float b = random_float(s); return b * (mx - mn) + mn; }
 DEV int random_int(Rng &s, int mn, int mx) { /* rng.cuh:31-42 */
     float random = curand_uniform_f(s);

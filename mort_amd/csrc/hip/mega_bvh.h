@@ -185,9 +185,13 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
 #define PROFS(i) do { ps1 = __builtin_readcyclecounter(); profc[i] += ps1 - ps0; ps0 = ps1; } while (0)
     unsigned long long pt0 = __builtin_readcyclecounter(), pt1;
 #define PROF(i, lanes) do { prof[2 * (i)] += 1; prof[2 * (i) + 1] += (unsigned long long)(lanes); } while (0)
+    unsigned long long profb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* S branches: steps entered, lanes: metal, dielectric, lambertian, finish, get_ray, unwind iterations */
+#define PROFB(i) do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { \
+        atomicAdd(&a.counters[18 + 2 * (i)], 1ull); atomicAdd(&a.counters[19 + 2 * (i)], (unsigned long long)__popcll(m_)); } } while (0)
 #define PROFC(i) do { pt1 = __builtin_readcyclecounter(); profc[i] += pt1 - pt0; pt0 = pt1; } while (0)
 #else
 #define PROF(i, lanes) do { } while (0)
+#define PROFB(i) do { } while (0)
 #define PROFC(i) do { } while (0)
 #define PROFS0() do { } while (0)
 #define PROFS(i) do { } while (0)
@@ -302,12 +306,14 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         const int mtype = DREF_TYPE(sp.mat), midx = DREF_IDX(sp.mat);
                         StackEntry e;
                         if (mtype == MORT_MAT_METAL) { /* materials.cuh:73-84 */
+                            PROFB(0);
                             const DMetal m = metal[midx];
                             V3 reflected = reflect(ray.d, normal);
                             reflected = vadd(vunit(reflected), vscale(m.fuzz, random_unit_vector(rng)));
                             ray.o = p; ray.d = reflected;
                             e.kx = 1.0f * m.r; e.ky = 1.0f * m.g; e.kz = 1.0f * m.b; e.rp = 1.0f;
                         } else if (mtype == MORT_MAT_DIELECTRIC) { /* materials.cuh:107-130 */
+                            PROFB(1);
                             const DDielectric m = dielectric[midx];
                             const float refraction_ratio = front_face ? m.inv_ior : m.ior;
                             const V3 unit_direction = vunit(ray.d);
@@ -323,6 +329,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             e.kx = 1.0f; e.ky = 1.0f; e.kz = 1.0f; e.rp = 1.0f;
                             ident_mask |= (1ull << iter);
                         } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
+                            PROFB(2);
                             const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
                             const DLambert m = lamb ? lambert[midx] : isotropic[midx];
                             V3 attenuation = mk(m.r, m.g, m.b);
@@ -386,14 +393,23 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                 }
                 PROFS(4);
                 if (kind == K_FINISH) { /* unwind + accumulate (camera.cuh:165-173,190) */
-                    while (iter > 0) {
-                        iter--;
-                        if ((ident_mask >> iter) & 1ull) { final_value = vadd(mk(0, 0, 0), final_value); continue; }
-                        StackEntry e;
-                        if (iter < DL) { const float4 e4 = stack_lds[iter * BLOCK + threadIdx.x]; e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w; }
-                        else e = stack_deep[iter];
-                        const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
-                        final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
+                    PROFB(3);
+                    /* an identity (dielectric) level is final = 0 + final: it only turns -0 into +0, and every level
+                     * leaves a value without -0, so only an identity level that comes FIRST (deepest) can matter;
+                     * the loop visits the stored levels alone, deepest first */
+                    if (iter > 0) {
+                        unsigned long long todo = ~ident_mask & (iter >= 64 ? ~0ull : ((1ull << iter) - 1ull));
+                        if ((ident_mask >> (iter - 1)) & 1ull) final_value = vadd(mk(0, 0, 0), final_value);
+                        while (todo != 0ull) {
+                            const int lvl = 63 - __builtin_clzll(todo);
+                            todo &= ~(1ull << lvl);
+                            StackEntry e;
+                            if (lvl < DL) { const float4 e4 = stack_lds[lvl * BLOCK + threadIdx.x]; e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w; }
+                            else e = stack_deep[lvl];
+                            const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
+                            final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
+                        }
+                        iter = 0;
                     }
                     ident_mask = 0ull;
                     pixel_color = vadd(pixel_color, final_value);
@@ -473,6 +489,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                 PROFS(6);
                 if (state != ST_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
+                        PROFB(4);
                         ray = get_ray(a, x, y, rng, s_i, s_j);
                         ray_time0 = ray.tm;
                         iter = 0;
@@ -516,6 +533,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
         for (int k = 0; k < 6; k++) atomicAdd(&a.counters[4 + k], prof[k]);
         for (int k = 0; k < 4; k++) atomicAdd(&a.counters[10 + k], profc[k]);
         for (int k = 4; k < 8; k++) atomicAdd(&a.counters[14 + k - 4], profc[k]);
+        (void)profb;
 #endif
     }
 }

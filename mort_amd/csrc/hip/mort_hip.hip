@@ -966,6 +966,13 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             std::fprintf(stderr, "[cycles] T %.1f%% (%.0f/step)  L %.1f%% (%.0f/step)  S %.1f%% (%.0f/step)  sched %.1f%%  total wave-cycles %.3g\n",
                          100.0 * cnt[10] / tot, (double)cnt[10] / (double)cnt[4], 100.0 * cnt[11] / tot, (double)cnt[11] / (double)cnt[6],
                          100.0 * cnt[12] / tot, (double)cnt[12] / (double)cnt[8], 100.0 * cnt[13] / tot, tot);
+            {
+                const char *bn[6] = {"metal", "dielectric", "lambertian", "finish", "get_ray", "unwind iteration"};
+                for (int k = 0; k < 6; k++)
+                    std::fprintf(stderr, "[S branch] %-16s entered in %5.1f%% of S steps (x%.2f), %4.1f lanes when entered\n", bn[k],
+                                 100.0 * (double)cnt[18 + 2 * k] / (double)cnt[8], (double)cnt[18 + 2 * k] / (double)cnt[8],
+                                 cnt[18 + 2 * k] ? (double)cnt[19 + 2 * k] / (double)cnt[18 + 2 * k] : 0.0);
+            }
             std::fprintf(stderr, "[S parts, cycles/step] shade %.0f  finish %.0f  newpix %.0f  newsample+setup %.0f\n", (double)cnt[14] / (double)cnt[8],
                          (double)cnt[15] / (double)cnt[8], (double)cnt[16] / (double)cnt[8], (double)cnt[17] / (double)cnt[8]);
         }

@@ -106,3 +106,21 @@ def test_uniform_and_random_float_ranges(oracle):
     # extreme outputs: x = 0xffffffff -> uniform 1.0 -> random_float 0.0; x = 0 -> 2^-33 -> random_float rounds to 1.0
     assert np.float32(np.float32(4294967295) * np.float32(2.3283064e-10) + np.float32(2.3283064e-10) / np.float32(2)) == np.float32(1.0)
     assert np.float32(1.0 - float(np.float32(2.3283064e-10) / np.float32(2))) == np.float32(1.0)
+
+
+def test_random_float_single_rounding():
+    """dev_math.h computes rng.cuh:17-23's (float)(1.0 - (double)u) as the fp32 subtraction 1.0f - u.
+
+    Identical for every generator output (a C loop over all 2^32 agrees); here: both ends of the range,
+    every output that lands near a binade boundary of u, and a stride over the rest.
+    """
+    edges = np.concatenate([np.arange(0, 1 << 21, dtype=np.uint64), np.arange((1 << 32) - (1 << 21), 1 << 32, dtype=np.uint64)])
+    pows = np.concatenate([np.arange(max(0, (1 << k) - 4096), (1 << k) + 4096, dtype=np.uint64) for k in range(8, 32)])
+    stride = np.arange(0, 1 << 32, 257, dtype=np.uint64)
+    for xs in (edges, pows, stride):
+        x = xs.astype(np.uint32)
+        u = x.astype(np.float32) * np.float32(2.3283064e-10) + np.float32(2.3283064e-10) / np.float32(2.0)
+        assert u.dtype == np.float32
+        via_f64 = (1.0 - u.astype(np.float64)).astype(np.float32)
+        direct = np.float32(1.0) - u
+        assert np.array_equal(via_f64.view(np.uint32), direct.view(np.uint32))
