@@ -156,10 +156,10 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
 
     /* per-lane state */
     int state = ST_S, kind = K_NEWPIX;
-    int x = 0, y = 0, lofs = 0;
+    int xy = 0, lofs = 0; /* x | y << 16 */
     Rng rng; rng.d = rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = 0; rng.draws = 0;
     V3 pixel_color = mk(0, 0, 0);
-    int s = 0, s_i = 0, s_j = 0, iter = 0;
+    int s_ij = 0, iter = 0; /* stratum s_i | s_j << 16; the sample index is s_j * sqrt_spp + s_i */
     uint32_t segments = 0;
     Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.tm = 0;
     float ray_time0 = 0;
@@ -168,9 +168,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
     int best = -1;         /* sphere | leaf << 16 of the closest hit so far */
     uint32_t node = 0;     /* T: own-tree node; L: leaf record */
     int sp = 0, flags = 0; /* pending far children; FL_TIE / FL_REF */
-    unsigned fallbacks = 0;
     V3 final_value = mk(0, 0, 0);
-    unsigned long long tot_segments = 0, tot_draws = 0;
     StackEntry stack_deep[MORT_MAX_BOUNCE_LIMIT]; /* private overflow, touched only by paths deeper than the LDS part */
     /* bit i set: bounce level i is a dielectric scatter, whose entry (k = (1,1,1), 1/pdf = 1) unwinds as
      * final = 0 + 1*((1,1,1)*final) = 0 + final exactly -- such levels are neither stored nor loaded */
@@ -274,7 +272,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     bool need_ref = flags != 0;
                     if (!need_ref && best >= 0) need_ref = !slab_check(leaves[best >> 16], ray, orr, closest);
                     if (need_ref) { /* the reference's walk (objects.cuh:664-723) over its own threaded nodes */
-                        fallbacks++;
+                        atomicAdd(&a.counters[3], 1ull); /* rare: about one segment in 10^5 */
                         closest = __builtin_inff(); best = -1;
                         const double dix = 1.0 / (double)ray.d.x, diy = 1.0 / (double)ray.d.y, diz = 1.0 / (double)ray.d.z;
                         int n = node_first;
@@ -413,10 +411,9 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     }
                     ident_mask = 0ull;
                     pixel_color = vadd(pixel_color, final_value);
-                    s++;
-                    s_i++;
-                    if (s_i == a.sqrt_spp) { s_i = 0; s_j++; }
-                    if (s < spp) {
+                    s_ij++;
+                    if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
+                    if ((s_ij >> 16) < a.sqrt_spp) {
                         kind = K_NEWSAMPLE;
                     } else { /* camera.cuh:194-207 */
                         V3 c = vscale(a.pixel_samples_scale, pixel_color);
@@ -446,7 +443,9 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
                             a.states[lofs] = st;
                         }
-                        tot_segments += segments; tot_draws += rng.draws;
+                        /* per-pixel totals straight to the counters (two atomics per pixel; no lane-resident totals) */
+                        atomicAdd(&a.counters[0], (unsigned long long)segments);
+                        atomicAdd(&a.counters[1], (unsigned long long)rng.draws);
                         kind = K_NEWPIX;
                     }
                 }
@@ -468,8 +467,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         const int tx = tile % fa.tiles_x, ty = tile / fa.tiles_x;
                         const int qx = tx * 8 + (within & 7), qly = ty * 8 + (within >> 3);
                         if (qx < a.width && qly < a.local_rows) {
-                            x = qx;
-                            y = global_row(qly, a.rank, a.nranks, a.rows_per_block);
+                            xy = qx | (global_row(qly, a.rank, a.nranks, a.rows_per_block) << 16);
                             lofs = qx + qly * a.width;
                             got = true;
                         }
@@ -479,7 +477,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         rng.d = st.d; rng.v0 = st.v[0]; rng.v1 = st.v[1]; rng.v2 = st.v[2]; rng.v3 = st.v[3]; rng.v4 = st.v[4];
                         rng.draws = 0;
                         pixel_color = mk(0, 0, 0);
-                        s = 0; s_i = 0; s_j = 0; segments = 0;
+                        s_ij = 0; segments = 0;
                         kind = (spp > 0) ? K_NEWSAMPLE : K_FINISH;
                         if (spp <= 0) { /* degenerate: zero samples -> 0 * inf = NaN -> 0 */
                             final_value = mk(0, 0, 0);
@@ -490,7 +488,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                 if (state != ST_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
                         PROFB(4);
-                        ray = get_ray(a, x, y, rng, s_i, s_j);
+                        ray = get_ray(a, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
                         ray_time0 = ray.tm;
                         iter = 0;
                         kind = K_SHADE;
@@ -518,17 +516,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
             PROFC(2);
         }
     }
-    /* per-wave totals */
-    unsigned long long fb_total = fallbacks;
-    for (int off = 32; off > 0; off >>= 1) {
-        tot_segments += __shfl_down(tot_segments, off);
-        tot_draws += __shfl_down(tot_draws, off);
-        fb_total += __shfl_down(fb_total, off);
-    }
     if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&a.counters[0], tot_segments);
-        atomicAdd(&a.counters[1], tot_draws);
-        if (fb_total) atomicAdd(&a.counters[3], fb_total);
 #ifdef MORT_PROFILE_STATES
         for (int k = 0; k < 6; k++) atomicAdd(&a.counters[4 + k], prof[k]);
         for (int k = 0; k < 4; k++) atomicAdd(&a.counters[10 + k], profc[k]);

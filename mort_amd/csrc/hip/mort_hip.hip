@@ -818,7 +818,8 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     const int waves_per_block = 4;
     const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
     const char *force = std::getenv("MORT_FORCE_GENERIC");
-    const bool use_fast = c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->bounce_limit >= 1 &&
+    const bool use_fast = c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 32768 && cam->bounce_limit >= 1 &&
+                          W < 65536 && H < 32768 &&
                           !(force && force[0] == '1');
     int lds_bytes_used = 0;
     const void *fast_kernel_used = nullptr;
