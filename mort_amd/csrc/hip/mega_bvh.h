@@ -68,6 +68,45 @@ enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
 enum { FL_TIE = 1, FL_REF = 2 };
 
 DEV bool own_inv_ok(float v) { const float a = mort_fabsf(v); return a > 1e-15f && a < 1e15f; } /* !(NaN) too */
+/* Textures whose tables stay in HBM (image, noise) and the error pattern, with the sphere uv they read: rare in
+ * the scenes this kernel serves, kept out of line so that their registers and code stay out of the shade step */
+struct V3Ret { float x, y, z; };
+__device__ __attribute__((noinline)) V3Ret texture_value_uv(const DScene *sc, uint32_t tex, float nx, float ny, float nz, float px, float py, float pz) {
+    float u, v;
+    sphere_uv(mk(nx, ny, nz), u, v);
+    const V3 c = texture_value(*sc, tex, u, v, mk(px, py, pz));
+    V3Ret r; r.x = c.x; r.y = c.y; r.z = c.z;
+    return r;
+}
+
+/* bvh_node::hit as the reference walks it (objects.cuh:664-723): its threaded nodes (HBM), left first, aabb::hit
+ * evaluated exactly.  Out of line: it runs for about one segment in 10^5. */
+struct RefHit { int best; float closest; };
+__device__ __attribute__((noinline)) RefHit reference_walk(const DBvhNode *nodes, int node_first, int node_end, const DSphere *spheres,
+                                                           float ox, float oy, float oz, float dx, float dy, float dz, float tm, float ray_a) {
+    Ray ray; ray.o = mk(ox, oy, oz); ray.d = mk(dx, dy, dz); ray.tm = tm;
+    float closest = __builtin_inff();
+    int best = -1;
+    const double dix = 1.0 / (double)ray.d.x, diy = 1.0 / (double)ray.d.y, diz = 1.0 / (double)ray.d.z;
+    int n = node_first;
+    while (n < node_end) {
+        const DBvhNode nd = nodes[n];
+        const int skip = (int)(nd.skip & 0x7fffffffu);
+        if (!slab_exact(nd, ray.o.x, ray.o.y, ray.o.z, dix, diy, diz, closest)) { n = skip; continue; }
+        if (!(nd.skip >> 31)) { n = n + 1; continue; }
+        const uint32_t pa = nd.prims & 0x7fffu, pb = (nd.prims >> 16) & 0x7fffu;
+        for (int k = 0; k < 2; k++) {
+            const uint32_t p = k ? pb : pa;
+            if (k == 1 && pb == pa) break;
+            float t;
+            if (sphere_hit_t(spheres[p], ray, ray_a, 0.001f, closest, t)) { closest = t; best = (int)p; }
+        }
+        n = skip;
+    }
+    RefHit h; h.best = best; h.closest = closest;
+    return h;
+}
+
 /* per-ray constants of the own-tree box test: p = b * inv - o * inv */
 struct OwnRay { float ix, iy, iz, mx, my, mz, band, invlen; };
 
@@ -271,25 +310,11 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     /* is the winner what bvh_node::hit returns?  (header comment) */
                     bool need_ref = flags != 0;
                     if (!need_ref && best >= 0) need_ref = !slab_check(leaves[best >> 16], ray, orr, closest);
-                    if (need_ref) { /* the reference's walk (objects.cuh:664-723) over its own threaded nodes */
-                        atomicAdd(&a.counters[3], 1ull); /* rare: about one segment in 10^5 */
-                        closest = __builtin_inff(); best = -1;
-                        const double dix = 1.0 / (double)ray.d.x, diy = 1.0 / (double)ray.d.y, diz = 1.0 / (double)ray.d.z;
-                        int n = node_first;
-                        while (n < node_end) {
-                            const DBvhNode nd = a.sc.nodes[n];
-                            const int skip = (int)(nd.skip & 0x7fffffffu);
-                            if (!slab_exact(nd, ray.o.x, ray.o.y, ray.o.z, dix, diy, diz, closest)) { n = skip; continue; }
-                            if (!(nd.skip >> 31)) { n = n + 1; continue; }
-                            const uint32_t pa = nd.prims & 0x7fffu, pb = (nd.prims >> 16) & 0x7fffu;
-                            for (int k = 0; k < 2; k++) {
-                                const uint32_t p = k ? pb : pa;
-                                if (k == 1 && pb == pa) break;
-                                float t;
-                                if (sphere_hit_t(spheres[p], ray, ray_a, 0.001f, closest, t)) { closest = t; best = (int)p; }
-                            }
-                            n = skip;
-                        }
+                    if (need_ref) { /* rare (about one segment in 10^5): the reference's own walk */
+                        atomicAdd(&a.counters[3], 1ull);
+                        const RefHit h = reference_walk(a.sc.nodes, node_first, node_end, spheres, ray.o.x, ray.o.y, ray.o.z,
+                                                        ray.d.x, ray.d.y, ray.d.z, ray.tm, ray_a);
+                        best = h.best; closest = h.closest;
                     }
                     if (best >= 0) best &= 0x7fff;
                     if (best < 0) { /* camera.cuh:154-158 */
@@ -346,9 +371,8 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                                     } else break;
                                 }
                                 if (!resolved) { /* image / noise / error pattern: tables stay in HBM */
-                                    float u, v;
-                                    sphere_uv(outward, u, v);
-                                    attenuation = texture_value(a.sc, tex, u, v, p);
+                                    const V3Ret c = texture_value_uv(&a.sc, tex, outward.x, outward.y, outward.z, p.x, p.y, p.z);
+                                    attenuation = mk(c.x, c.y, c.z);
                                 }
                             }
                             V3 dir;
@@ -374,7 +398,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             if (mtype == MORT_MAT_DIFFUSE_LIGHT && front_face) {
                                 const DLambert m = dlight[midx];
                                 if (m.tex == 0) emission = mk(m.r, m.g, m.b);
-                                else { float u, v; sphere_uv(outward, u, v); emission = texture_value(a.sc, m.tex, u, v, p); }
+                                else { const V3Ret c = texture_value_uv(&a.sc, m.tex, outward.x, outward.y, outward.z, p.x, p.y, p.z); emission = mk(c.x, c.y, c.z); }
                             }
                             final_value = emission;
                             kind = K_FINISH;
