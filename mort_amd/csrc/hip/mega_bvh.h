@@ -66,6 +66,13 @@ struct FastArgs {
 
 enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
 enum { FL_TIE = 1, FL_REF = 2 };
+/* -DMORT_REGION_MARKS: comments in the ISA at region boundaries, for static instruction counts per region
+ * (scripts/isa_regions.py) */
+#ifdef MORT_REGION_MARKS
+#define REGION(name) asm volatile("; REGION " name)
+#else
+#define REGION(name) do { } while (0)
+#endif
 
 DEV bool own_inv_ok(float v) { const float a = mort_fabsf(v); return a > 1e-15f && a < 1e15f; } /* !(NaN) too */
 /* Textures whose tables stay in HBM (image, noise) and the error pattern, with the sphere uv they read: rare in
@@ -216,6 +223,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
     const int DL = fa.stack_lds_depth;
 #ifdef MORT_PROFILE_STATES
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}; /* steps/lanes for T, L, S (wave-uniform) */
+    unsigned long long prof_truns = 0;
     unsigned long long profc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* cycles in T, L, S, scheduler; S parts: shade, finish, newpix, setup */
     unsigned long long ps0 = 0, ps1;
 #define PROFS0() do { ps0 = __builtin_readcyclecounter(); } while (0)
@@ -247,9 +255,13 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
         else pick = (nL >= nS) ? ST_L : ST_S;
         PROFC(3);
 
+                REGION("T");
         if (pick == ST_T) {
             /* ---- own-tree steps: both child boxes of one node, near child next, far child pushed ---- */
             int keep;
+#ifdef MORT_PROFILE_STATES
+            prof_truns++;
+#endif
             do {
                 PROF(0, __popcll(__ballot(state == ST_T)));
                 if (state == ST_T) {
@@ -277,6 +289,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
             } while (keep >= t_keep);
             PROFC(0);
         } else if (pick == ST_L) {
+                REGION("L");
             /* ---- leaf: sphere::hit on the one or two spheres of a reference leaf node (objects.cuh:60-77,690-692) ---- */
             PROF(1, nL);
             if (state == ST_L) {
@@ -305,6 +318,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
             /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
             PROF(2, nS);
             PROFS0();
+                REGION("S:verify");
             if (state == ST_S) {
                 if (kind == K_SHADE) {
                     /* is the winner what bvh_node::hit returns?  (header comment) */
@@ -316,6 +330,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                                                         ray.d.x, ray.d.y, ray.d.z, ray.tm, ray_a);
                         best = h.best; closest = h.closest;
                     }
+                REGION("S:hitrecord");
                     if (best >= 0) best &= 0x7fff;
                     if (best < 0) { /* camera.cuh:154-158 */
                         final_value = a.background;
@@ -329,6 +344,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         const int mtype = DREF_TYPE(sp.mat), midx = DREF_IDX(sp.mat);
                         StackEntry e;
                         if (mtype == MORT_MAT_METAL) { /* materials.cuh:73-84 */
+                REGION("S:metal");
                             PROFB(0);
                             const DMetal m = metal[midx];
                             V3 reflected = reflect(ray.d, normal);
@@ -336,6 +352,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             ray.o = p; ray.d = reflected;
                             e.kx = 1.0f * m.r; e.ky = 1.0f * m.g; e.kz = 1.0f * m.b; e.rp = 1.0f;
                         } else if (mtype == MORT_MAT_DIELECTRIC) { /* materials.cuh:107-130 */
+                REGION("S:dielectric");
                             PROFB(1);
                             const DDielectric m = dielectric[midx];
                             const float refraction_ratio = front_face ? m.inv_ior : m.ior;
@@ -352,6 +369,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             e.kx = 1.0f; e.ky = 1.0f; e.kz = 1.0f; e.rp = 1.0f;
                             ident_mask |= (1ull << iter);
                         } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
+                REGION("S:lambertian");
                             PROFB(2);
                             const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
                             const DLambert m = lamb ? lambert[midx] : isotropic[midx];
@@ -375,6 +393,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                                     attenuation = mk(c.x, c.y, c.z);
                                 }
                             }
+                REGION("S:lamb_scatter");
                             V3 dir;
                             float mat_pdf, scattering_pdf;
                             if (lamb) {
@@ -394,6 +413,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             e.kx = scattering_pdf * attenuation.x; e.ky = scattering_pdf * attenuation.y; e.kz = scattering_pdf * attenuation.z;
                             e.rp = 1 / mat_pdf;
                         } else { /* diffuse_light or unknown tag: no scatter (materials.cuh:151-163) */
+                REGION("S:light");
                             V3 emission = mk(0, 0, 0);
                             if (mtype == MORT_MAT_DIFFUSE_LIGHT && front_face) {
                                 const DLambert m = dlight[midx];
@@ -403,6 +423,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             final_value = emission;
                             kind = K_FINISH;
                         }
+                REGION("S:stackstore");
                         if (kind == K_SHADE) {
                             if (!((ident_mask >> iter) & 1ull)) {
                                 if (iter < DL) { float4 e4; e4.x = e.kx; e4.y = e.ky; e4.z = e.kz; e4.w = e.rp; stack_lds[iter * BLOCK + threadIdx.x] = e4; }
@@ -413,6 +434,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         }
                     }
                 }
+                REGION("S:finish");
                 PROFS(4);
                 if (kind == K_FINISH) { /* unwind + accumulate (camera.cuh:165-173,190) */
                     PROFB(3);
@@ -473,6 +495,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         kind = K_NEWPIX;
                     }
                 }
+                REGION("S:newpix");
                 PROFS(5);
                 if (kind == K_NEWPIX) {
                     /* one atomicAdd per wave per refill; lanes take consecutive slots in 8x8-tile order */
@@ -508,6 +531,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         }
                     }
                 }
+                REGION("S:getray");
                 PROFS(6);
                 if (state != ST_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
@@ -518,6 +542,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         kind = K_SHADE;
                         if (a.bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
                     }
+                REGION("S:setup");
                     if (kind == K_SHADE) { /* start world::hit for the new ray */
                         ray_a = vlen2(ray.d);
                         orr.ix = 1.0f / ray.d.x; orr.iy = 1.0f / ray.d.y; orr.iz = 1.0f / ray.d.z;
@@ -536,6 +561,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     /* kind == K_FINISH here (bounce_limit 0 or spp 0): stays in ST_S for the next S step */
                 }
             }
+                REGION("S:end");
             PROFS(7);
             PROFC(2);
         }
@@ -543,6 +569,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
     if ((threadIdx.x & 63) == 0) {
 #ifdef MORT_PROFILE_STATES
         for (int k = 0; k < 6; k++) atomicAdd(&a.counters[4 + k], prof[k]);
+        atomicAdd(&a.counters[30], prof_truns);
         for (int k = 0; k < 4; k++) atomicAdd(&a.counters[10 + k], profc[k]);
         for (int k = 4; k < 8; k++) atomicAdd(&a.counters[14 + k - 4], profc[k]);
         (void)profb;

@@ -963,6 +963,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             for (int k = 0; k < 3; k++)
                 std::fprintf(stderr, "[states] %s: %llu wave-steps, %llu lane-steps, utilisation %.1f%%\n", nm[k], cnt[4 + 2 * k], cnt[5 + 2 * k],
                              cnt[4 + 2 * k] ? 100.0 * (double)cnt[5 + 2 * k] / (64.0 * (double)cnt[4 + 2 * k]) : 0.0);
+            std::fprintf(stderr, "[states] box-step runs: %llu (%.1f steps per run)\n", cnt[30], cnt[30] ? (double)cnt[4] / (double)cnt[30] : 0.0);
             const double tot = (double)(cnt[10] + cnt[11] + cnt[12] + cnt[13]);
             std::fprintf(stderr, "[cycles] T %.1f%% (%.0f/step)  L %.1f%% (%.0f/step)  S %.1f%% (%.0f/step)  sched %.1f%%  total wave-cycles %.3g\n",
                          100.0 * cnt[10] / tot, (double)cnt[10] / (double)cnt[4], 100.0 * cnt[11] / tot, (double)cnt[11] / (double)cnt[6],
