@@ -58,7 +58,9 @@ struct FastArgs {
     int tiles_x, tiles_total;
     uint32_t off_stack;   /* LDS offset of the per-lane bounce stacks: [depth][thread] float4 */
     int stack_lds_depth;  /* entries per lane kept in LDS; deeper entries spill to private memory */
-    const unsigned *tile_order; /* tiles in the order lanes should take them (most expensive first), or null = row-major */
+    const unsigned *tile_order; /* tiles by decreasing cost, or null = row-major */
+    int gen_tiles;              /* tiles per generation of the slot -> pixel map (below); 0 = plain order */
+    int spread_shift;           /* log2 of the pixels a wave takes from one tile (6 = whole tiles ... 0 = single pixels) */
     unsigned *tile_cost;        /* per tile: segments traced this frame (feeds the next frame's order), or null */
     int th_s, th_l, t_keep; /* scheduling thresholds (lanes): batch sizes that trigger a shade / leaf step, and the
                                lane count below which the box-step loop hands control back (wave-uniform) */
@@ -155,13 +157,13 @@ DEV bool slab_check(const DBvhNode &nd, const Ray &ray, const OwnRay &r, float c
 enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 
 #ifndef MORT_TH_S
-#define MORT_TH_S 32
+#define MORT_TH_S 40
 #endif
 #ifndef MORT_TH_L
 #define MORT_TH_L 24
 #endif
 #ifndef MORT_T_KEEP
-#define MORT_T_KEEP 16
+#define MORT_T_KEEP 8
 #endif
 
 #ifndef MORT_MIN_WAVES
@@ -509,7 +511,22 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                         base = __shfl(base, __ffsll((long long)need) - 1);
                         const unsigned q = base + (unsigned)rank;
                         if (q >= total_q) { state = ST_DONE; got = true; break; }
-                        const int tslot = (int)(q >> 6), within = (int)(q & 63u);
+                        /* slot -> (tile rank, pixel of the tile).  A lane's chain advances one segment per round of its
+                         * wave's state loop, and a round is slowest when all 64 lanes carry long chains; neighbouring
+                         * pixels, on the other hand, keep a wave's rays coherent.  So the 64 slots of one fetch are
+                         * 64 >> spread_shift groups of neighbouring pixels, spread evenly over a whole GENERATION of the
+                         * cost order (the gen_tiles tiles that the chip's lanes take at once).  Generation g, chunk w,
+                         * group u -> tile rank g*G + (w + u*S) mod G, pixel group u of that tile: a rotation per u,
+                         * hence a bijection between slots and pixels. */
+                        int tslot = (int)(q >> 6), within = (int)(q & 63u);
+                        if (fa.gen_tiles > 0) {
+                            const int g = tslot / fa.gen_tiles, w = tslot - g * fa.gen_tiles;
+                            const int left = fa.tiles_total - g * fa.gen_tiles;
+                            const int G = left < fa.gen_tiles ? left : fa.gen_tiles;
+                            const int groups = 64 >> fa.spread_shift, u = within >> fa.spread_shift;
+                            const int S = G >= groups ? G / groups : 1;
+                            tslot = g * fa.gen_tiles + (int)(((unsigned)w + (unsigned)u * (unsigned)S) % (unsigned)G);
+                        }
                         const int tile = fa.tile_order ? (int)fa.tile_order[tslot] : tslot;
                         const int tx = tile % fa.tiles_x, ty = tile / fa.tiles_x;
                         const int qx = tx * 8 + (within & 7), qly = ty * 8 + (within >> 3);

@@ -843,9 +843,10 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         fa.node_first = 0; fa.node_count = c->sc.n_nodes; /* the reference's threaded nodes (HBM): fallback walk */
         fa.next_q = (unsigned int *)(c->d_counters + 2);
         fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
+        const long long lanes_wanted = (long long)tiles * 64;
+        const double px_per_lane = (double)lanes_wanted / ((double)c->num_cus * 768.0);
         /* workgroup size: the largest of {768, 512, 384, 256} that still gives every CU a workgroup
          * (a rank of an 8-way partition owns ~100 k pixels: 768-thread groups would leave half the CUs idle) */
-        const long long lanes_wanted = (long long)tiles * 64;
         int FB = MORT_FAST_BLOCK;
         const char *fb_env = std::getenv("MORT_FAST_BLOCK_SIZE");
         if (fb_env) FB = std::atoi(fb_env);
@@ -861,13 +862,11 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         case 384: kern = mega_bvh_kernel<384, false>; kern_probe = mega_bvh_kernel<384, true>; break;
         default: FB = 256; kern = mega_bvh_kernel<256, false>; kern_probe = mega_bvh_kernel<256, true>; break;
         }
-        /* scheduling thresholds: batch for throughput when every lane has several pixels queued behind it, react fast
-         * (small batches) when a rank owns about one pixel per lane and the frame is bound by its longest pixel chain */
+        /* scheduling thresholds (mega_bvh.h).  Smaller batches do not help a chain-bound partition: measured on
+         * one rank of 8, (32,24,16) 100 ms, (12,12,8) 126 ms, (2,2,2) 192 ms -- a lane waits through every step
+         * its wave runs for other lanes, and small batches mean more of those */
         {
-            const double px_per_lane = (double)lanes_wanted / ((double)c->num_cus * 768.0);
             fa.th_s = MORT_TH_S; fa.th_l = MORT_TH_L; fa.t_keep = MORT_T_KEEP;
-            if (px_per_lane < 1.5) { fa.th_s = 12; fa.th_l = 12; fa.t_keep = 8; }
-            else if (px_per_lane < 2.5) { fa.th_s = 24; fa.th_l = 16; fa.t_keep = 12; }
             const char *th = std::getenv("MORT_THRESHOLDS"); /* "s,l,k" */
             if (th) { int s_ = 0, l_ = 0, k_ = 0; if (std::sscanf(th, "%d,%d,%d", &s_, &l_, &k_) == 3) { fa.th_s = s_; fa.th_l = l_; fa.t_keep = k_; } }
         }
@@ -932,6 +931,10 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             HIPCHK(c, hipMemcpyAsync(c->d_tile_order, c->h_order.data(), (size_t)tiles * sizeof(unsigned), hipMemcpyHostToDevice, s));
             HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
             fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost;
+            fa.gen_tiles = grid * (FB / 64); /* one tile's worth of slots per wave in flight */
+            fa.spread_shift = px_per_lane < 1.5 ? 0 : 6; /* measured: whole tiles while lanes refill several times, single pixels otherwise */
+            { const char *sp = std::getenv("MORT_SPREAD_SHIFT"); if (sp) fa.spread_shift = std::atoi(sp); }
+            if (fa.spread_shift >= 6 || fa.spread_shift < 0) fa.gen_tiles = 0;
             if (stats) HIPCHK(c, hipEventRecord(c->ev0, s)); /* time the frame itself; ordering upkeep is reported by wall-clock benches */
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FB), lds_bytes, s, fa);

@@ -14,7 +14,8 @@ for n in ns:
     for r in ranks:
         ctx.set_partition(r, n, 8)
         ctx.rng_seed(69420, cam.image_width, cam.image_height)
-        out = ctx.render(cam, want_accum=False)
+        out = ctx.render(cam, want_accum=False)  # first frame: tiles ordered by the one-sample probe
+        out = ctx.render(cam, want_accum=False)  # steady state: ordered by the previous frame's costs
         worst = max(worst, out["stats"]["seconds"])
     base = base or worst * n
     print(f"N={n}: slowest rank {worst*1e3:.1f} ms  -> scaling efficiency {base / (n * worst) * 100:.1f}%  lds={out['stats']['kernel_lds_bytes']}", flush=True)
