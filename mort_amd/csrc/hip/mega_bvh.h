@@ -174,7 +174,8 @@ enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 #endif
 
 /* PROBE = true is the 1-sample cost probe (its own symbol, so profiles keep the frame kernel's durations apart) */
-template <int BLOCK, bool PROBE>
+/* DRAIN = true adds the drain mode below (chain-bound partitions; it costs the throughput-bound frame 5 % in registers) */
+template <int BLOCK, bool PROBE, bool DRAIN = false>
 __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const RenderArgs &a = fa.r;
@@ -244,6 +245,11 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
 #define PROFS(i) do { } while (0)
 #endif
 
+    /* Drain mode (wave-uniform).  Once the pixel pool is empty, throughput no longer matters to this wave,
+     * only when its last pixel finishes.  The lane that is furthest behind (fewest samples done) then decides which
+     * state runs next, so its chain advances at the pace of a wave that carries it alone; the other lanes advance
+     * whenever they share its state. */
+    int leader = -1;
     for (;;) {
         const unsigned long long mT = __ballot(state == ST_T);
         const unsigned long long mL = __ballot(state == ST_L);
@@ -255,6 +261,10 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
         else if (nL >= th_l) pick = ST_L;
         else if (nT > 0) pick = ST_T;
         else pick = (nL >= nS) ? ST_L : ST_S;
+        if (DRAIN && leader >= 0) {
+            const int ls = __builtin_amdgcn_readlane(state, leader);
+            if (ls <= ST_S) pick = ls;
+        }
         PROFC(3);
 
                 REGION("T");
@@ -288,6 +298,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     else { node = next & 0x7fffu; if (next & 0x8000u) state = ST_L; }
                 }
                 keep = __popcll(__ballot(state == ST_T));
+                if (DRAIN && leader >= 0) keep = (__builtin_amdgcn_readlane(state, leader) == ST_T) ? 64 : 0;
             } while (keep >= t_keep);
             PROFC(0);
         } else if (pick == ST_L) {
@@ -579,6 +590,12 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                 }
             }
                 REGION("S:end");
+            /* pool empty (some lane found no pixel): follow the lane with the fewest samples done */
+            if (DRAIN && __ballot(state == ST_DONE) != 0ull) {
+                unsigned key = (state <= ST_S) ? ((unsigned)((s_ij >> 16) * a.sqrt_spp + (s_ij & 0xffff)) << 6) | (threadIdx.x & 63u) : 0xffffffffu;
+                for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)key, off); key = o < key ? o : key; }
+                leader = (key == 0xffffffffu) ? -1 : __builtin_amdgcn_readfirstlane((int)(key & 63u));
+            }
             PROFS(7);
             PROFC(2);
         }

@@ -856,11 +856,14 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             for (int k = 0; k < 4; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; }
         }
         void (*kern)(const FastArgs) = nullptr, (*kern_probe)(const FastArgs) = nullptr;
+        /* chain-bound partition (about one pixel per lane or fewer): drain mode + spread fetches (mega_bvh.h) */
+        bool chain_bound = px_per_lane < 1.5;
+        { const char *cb = std::getenv("MORT_CHAIN_BOUND"); if (cb) chain_bound = cb[0] == '1'; }
         switch (FB) {
-        case 768: kern = mega_bvh_kernel<768, false>; kern_probe = mega_bvh_kernel<768, true>; break;
-        case 512: kern = mega_bvh_kernel<512, false>; kern_probe = mega_bvh_kernel<512, true>; break;
-        case 384: kern = mega_bvh_kernel<384, false>; kern_probe = mega_bvh_kernel<384, true>; break;
-        default: FB = 256; kern = mega_bvh_kernel<256, false>; kern_probe = mega_bvh_kernel<256, true>; break;
+        case 768: kern = chain_bound ? mega_bvh_kernel<768, false, true> : mega_bvh_kernel<768, false, false>; kern_probe = mega_bvh_kernel<768, true, false>; break;
+        case 512: kern = chain_bound ? mega_bvh_kernel<512, false, true> : mega_bvh_kernel<512, false, false>; kern_probe = mega_bvh_kernel<512, true, false>; break;
+        case 384: kern = chain_bound ? mega_bvh_kernel<384, false, true> : mega_bvh_kernel<384, false, false>; kern_probe = mega_bvh_kernel<384, true, false>; break;
+        default: FB = 256; kern = chain_bound ? mega_bvh_kernel<256, false, true> : mega_bvh_kernel<256, false, false>; kern_probe = mega_bvh_kernel<256, true, false>; break;
         }
         /* scheduling thresholds (mega_bvh.h).  Smaller batches do not help a chain-bound partition: measured on
          * one rank of 8, (32,24,16) 100 ms, (12,12,8) 126 ms, (2,2,2) 192 ms -- a lane waits through every step
@@ -932,7 +935,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
             HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
             fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost;
             fa.gen_tiles = grid * (FB / 64); /* one tile's worth of slots per wave in flight */
-            fa.spread_shift = px_per_lane < 1.5 ? 0 : 6; /* measured: whole tiles while lanes refill several times, single pixels otherwise */
+            fa.spread_shift = chain_bound ? 0 : 6; /* measured: whole tiles while lanes refill several times, single pixels otherwise */
             { const char *sp = std::getenv("MORT_SPREAD_SHIFT"); if (sp) fa.spread_shift = std::atoi(sp); }
             if (fa.spread_shift >= 6 || fa.spread_shift < 0) fa.gen_tiles = 0;
             if (stats) HIPCHK(c, hipEventRecord(c->ev0, s)); /* time the frame itself; ordering upkeep is reported by wall-clock benches */
