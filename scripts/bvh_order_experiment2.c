@@ -1,8 +1,9 @@
 /*
- * bvh_order_experiment2.c -- CPU study of the ordered walk that mega_bvh.h uses.
+ * bvh_order_experiment2.c -- CPU model of the ordered walk that mega_bvh.h uses; tests/test_own_tree_model.py
+ * runs it.
  * Own SAH tree over the reference's LEAF NODES (boxes bit-identical to the reference's), near-first walk with a stack,
  * pruned in fp32: "certain miss" (tau band) or "entered beyond closest by more than the anomaly margin"
- *      t_enter * (1 - 4e-3) - closest > E_X / |d|,  E_X = max leaf diagonal below X + 4e-3 * diagonal of X.
+ *      t_enter * (1 - 8e-3) - closest > E_X / |d|,  E_X = max leaf diagonal below X + 8e-3 * diagonal of X.
  * The winner (min t over every sphere hit seen, ties flagged) is checked once against the reference's box test of its
  * leaf node at t_max = t; failure or a tie sends the ray to the reference walk.  Counts steps and verifies that every
  * ray that is not sent to the reference walk agrees with it.
@@ -21,7 +22,7 @@ typedef struct { box3 b; int left, right; int leaf; float E; } onode; /* leaf >=
 static onode *T; static int nT;
 static int nleaves; static box3 *lbox; static int *lnode, *lA, *lB;
 static const mort_bvh *RB; static const mort_world *W;
-static int opt_popcull = 1, opt_margin = 1;
+static int opt_popcull = 0, opt_margin = 1; /* the kernel does not re-test popped nodes */
 
 static box3 from_aabb(mort_aabb a) { box3 b = {{a.x.imin, a.y.imin, a.z.imin}, {a.x.imax, a.y.imax, a.z.imax}}; return b; }
 static box3 bunion(box3 a, box3 b) { for (int k = 0; k < 3; k++) { if (b.lo[k] < a.lo[k]) a.lo[k] = b.lo[k]; if (b.hi[k] > a.hi[k]) a.hi[k] = b.hi[k]; } return a; }
@@ -38,7 +39,7 @@ static int build(int *idx, int n) {
     int me = nT++;
     box3 b = lbox[idx[0]]; double ml = bdiag(lbox[idx[0]]);
     for (int i = 1; i < n; i++) { b = bunion(b, lbox[idx[i]]); double d = bdiag(lbox[idx[i]]); if (d > ml) ml = d; }
-    T[me].b = b; T[me].leaf = -1; T[me].E = (float)(ml * 1.001 + 4e-3 * bdiag(b));
+    T[me].b = b; T[me].leaf = -1; T[me].E = nextafterf((float)(ml * 1.001 + 8e-3 * bdiag(b)), INFINITY);
     if (n == 1) { T[me].leaf = idx[0]; return me; }
     double best = 1e300; int bax = 0, bsplit = n / 2;
     int *tmp = malloc(n * sizeof(int)); double *ra = malloc(n * sizeof(double));
@@ -58,18 +59,19 @@ static int build(int *idx, int n) {
 
 static unsigned long long n_rays, r_box, r_sph, r_leaf, v_steps, v_leaf, v_sph, v_fallback, v_mismatch, v_popcull, v_maxsp, hist_steps[64];
 
+/* mega_bvh.h own_prune, operation for operation (p = fma(b, inv, -o*inv); tau = 2^-20 max(|te|,|tx|) + band) */
+static float g_band, g_m[3];
 static int prune(const onode *nd, const float o[3], const float inv[3], float invlen, float closest, float *key) {
-    float te = 0.001f, tx = INFINITY, m = 0;
+    float te = 0.001f, tx = INFINITY;
+    (void)o;
     for (int k = 0; k < 3; k++) {
-        float p0 = (nd->b.lo[k] - o[k]) * inv[k], p1 = (nd->b.hi[k] - o[k]) * inv[k];
+        float p0 = fmaf(nd->b.lo[k], inv[k], -g_m[k]), p1 = fmaf(nd->b.hi[k], inv[k], -g_m[k]);
         te = fmaxf(te, fminf(p0, p1)); tx = fminf(tx, fmaxf(p0, p1));
-        m = fmaxf(m, fmaxf(fabsf(p0), fabsf(p1)));
     }
-    if (!(m < 1e30f)) { *key = -INFINITY; return 0; }
-    const float tau = m * 9.5367431640625e-07f;
-    if (tx - te < -tau) return 1; /* certain miss at t_max = inf */
-    *key = opt_margin ? te * (1.0f - 4e-3f) - nd->E * invlen - tau : te - tau;
-    return *key > closest;
+    const float tau = fmaf(fmaxf(fabsf(te), fabsf(tx)), 9.5367431640625e-07f, g_band);
+    const float k2 = opt_margin ? fmaf(te, 0.992f, -fmaf(nd->E, invlen, tau)) : te - tau;
+    *key = te;
+    return (tx - te < -tau) || (k2 > closest);
 }
 static float sph_t(const mort_sphere *s, const ray *r, float t_min, float t_max, int *ok) {
     hit_record rec; memset(&rec, 0, sizeof rec);
@@ -96,9 +98,11 @@ static void seg_hook(const void *wv, const void *rv, float t_min) {
     ref_walk(r, t_min, 0, &c_ref, &b_ref);
     const float o[3] = {r->orig.e[0], r->orig.e[1], r->orig.e[2]};
     float inv[3]; int deg = 0;
-    for (int k = 0; k < 3; k++) { inv[k] = (float)(1.0 / (double)r->dir.e[k]); float a = fabsf(inv[k]); if (!(a > 1e-30f && a < 1e30f)) deg = 1; }
-    if (deg) { v_fallback++; return; }
-    const float invlen = 1.0f / sqrtf(vlen2(r->dir)) * 1.001f;
+    for (int k = 0; k < 3; k++) { inv[k] = 1.0f / r->dir.e[k]; float a = fabsf(inv[k]); if (!(a > 1e-15f && a < 1e15f)) deg = 1; g_m[k] = o[k] * inv[k]; }
+    const float mm = fmaxf(fmaxf(fabsf(g_m[0]), fabsf(g_m[1])), fabsf(g_m[2]));
+    if (deg || !(mm < 1e30f)) { v_fallback++; return; }
+    g_band = mm * 4.76837158203125e-07f;
+    const float invlen = 1.01f / sqrtf(vlen2(r->dir));
     float cl = INFINITY; int bs = -1, bl = -1, tie = 0; int stk[64]; float stt[64]; int n = 0, c = 0; float key;
     unsigned long long steps = 0;
     if (prune(&T[0], o, inv, invlen, cl, &key)) c = -1;
@@ -129,12 +133,13 @@ static void seg_hook(const void *wv, const void *rv, float t_min) {
 }
 int main(int argc, char **argv) {
     int width = argc > 1 ? atoi(argv[1]) : 300, spp = argc > 2 ? atoi(argv[2]) : 4;
+    const int scene = argc > 5 ? atoi(argv[5]) : 1;
     if (argc > 3) opt_margin = atoi(argv[3]);
     if (argc > 4) opt_popcull = atoi(argv[4]);
     static mort_world w; mort_camera cam;
     mort_world_init(&w);
     mort_scene_opts opts; memset(&opts, 0, sizeof opts);
-    mort_scene_build(1, &w, &cam, &opts);
+    mort_scene_build(scene, &w, &cam, &opts);
     cam.image_width = width; cam.samples_per_pixel = spp;
     mort_camera_initialize(&cam);
     W = &w; RB = &w.objs.host_bvh[0];
