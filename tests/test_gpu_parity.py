@@ -184,6 +184,37 @@ def test_wavefront_mode_rejects_unsupported_scenes(gpu_ctx):
     assert e.value.status == -6
 
 
+@pytest.mark.parametrize("env", [
+    {"MORT_CHAIN_BOUND": "0"}, {"MORT_CHAIN_BOUND": "1"},
+    {"MORT_CHAIN_BOUND": "1", "MORT_SPREAD_SHIFT": "3"}, {"MORT_CHAIN_BOUND": "0", "MORT_SPREAD_SHIFT": "0"},
+    {"MORT_NO_TILE_ORDER": "1"}, {"MORT_THRESHOLDS": "2,2,2"}, {"MORT_THRESHOLDS": "64,64,64"},
+    {"MORT_FAST_BLOCK_SIZE": "256"}, {"MORT_FAST_BLOCK_SIZE": "512", "MORT_CHAIN_BOUND": "1"},
+])
+def test_scheduling_choices_do_not_reach_the_pixels(gpu_ctx, oracle, monkeypatch, env):
+    """Which lanes take which pixels, in which order, in which batch sizes and workgroup shapes (cost-ordered tiles,
+    spread fetches, drain mode, thresholds) must not change a bit of the result: Scene 1 at 400x225, two frames
+    (the second one ordered by the first one's costs), against the oracle."""
+    world, cam = host.build_scene(1, width=400, spp=9)
+    ref1 = oracle.render(world, cam, nthreads=8)
+    ref2 = oracle.render(world, cam, nthreads=8, states=ref1["states"].copy())
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    out1 = render_gpu(gpu_ctx, world, cam, oracle=oracle)
+    assert_same(out1, ref1)
+    out2 = gpu_ctx.render(cam, want_accum=True, want_segments=True)  # streams continue; tiles now ordered by frame 1
+    out2["states"] = gpu_ctx.rng_store(cam.image_width, cam.image_height, oracle.STATE_DTYPE)
+    assert_same(out2, ref2)
+
+
+def test_reference_walk_is_rare_and_counted(gpu_ctx, oracle):
+    """The BVH megakernel re-traces a ray with the reference's own walk when it cannot prove its winner
+    (DESIGN.md 4.2): a handful per million segments, reported in the stats."""
+    world, cam = host.build_scene(1, width=400, spp=16)
+    out = render_gpu(gpu_ctx, world, cam, oracle=oracle)
+    assert 0 <= out["stats"]["reference_walks"] < out["stats"]["segments"] // 10000
+    assert_same(out, oracle.render(world, cam, nthreads=8))
+
+
 def test_full_geometry_low_spp(gpu_ctx, oracle):
     """The headline geometry (Scene 1, 1200x675) at 4 spp against the oracle, bit for bit."""
     world, cam = host.build_scene(1, spp=4)
