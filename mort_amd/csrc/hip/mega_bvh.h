@@ -162,8 +162,11 @@ enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 #ifndef MORT_TH_L
 #define MORT_TH_L 24
 #endif
+#ifndef MORT_T_UNROLL
+#define MORT_T_UNROLL 2 /* box steps per check of the lane count */
+#endif
 #ifndef MORT_T_KEEP
-#define MORT_T_KEEP 8
+#define MORT_T_KEEP 12
 #endif
 
 #ifndef MORT_MIN_WAVES
@@ -275,6 +278,8 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
             prof_truns++;
 #endif
             do {
+#pragma unroll
+                for (int rep = 0; rep < MORT_T_UNROLL; rep++) {
                 PROF(0, __popcll(__ballot(state == ST_T)));
                 if (state == ST_T) {
                     const float4 *np = (const float4 *)(nodes2 + node);
@@ -296,6 +301,7 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     else have = false;
                     if (!have) { state = ST_S; kind = K_SHADE; }
                     else { node = next & 0x7fffu; if (next & 0x8000u) state = ST_L; }
+                }
                 }
                 keep = __popcll(__ballot(state == ST_T));
                 if (DRAIN && leader >= 0) keep = (__builtin_amdgcn_readlane(state, leader) == ST_T) ? 64 : 0;
