@@ -288,17 +288,14 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     const bool m0 = own_prune(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.z, orr, closest, te0);
                     const bool m1 = own_prune(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.w, orr, closest, te1);
                     const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-                    uint32_t next = 0;
-                    bool have = true;
-                    if (!m0 && !m1) {
-                        const bool first0 = te0 <= te1;
-                        next = first0 ? c0 : c1;
-                        tstack[sp * BLOCK] = (unsigned short)(first0 ? c1 : c0);
-                        sp++;
-                    } else if (!m0) next = c0;
-                    else if (!m1) next = c1;
-                    else if (sp > 0) { sp--; next = tstack[sp * BLOCK]; }
-                    else have = false;
+                    /* both hit: near child next, far child pushed; one hit: that child; none: pop, or done */
+                    const bool both = !m0 && !m1, none = m0 && m1;
+                    const bool first0 = te0 <= te1;
+                    uint32_t next = both ? (first0 ? c0 : c1) : (m0 ? c1 : c0);
+                    if (both) tstack[sp * BLOCK] = (unsigned short)(first0 ? c1 : c0);
+                    sp += both ? 1 : 0;
+                    const bool have = !none || sp > 0;
+                    if (none && sp > 0) { sp--; next = tstack[sp * BLOCK]; }
                     if (!have) { state = ST_S; kind = K_SHADE; }
                     else { node = next & 0x7fffu; if (next & 0x8000u) state = ST_L; }
                 }
