@@ -116,6 +116,24 @@ __device__ __attribute__((noinline)) RefHit reference_walk(const DBvhNode *nodes
     return h;
 }
 
+/* sphere::hit (objects.cuh:60-77) returning the accepted root, or -1 for "no hit" (an accepted root is >= t_min > 0 or
+ * NaN, never -1): the same operations as sphere_hit_t, without a result variable that is only sometimes written
+ * (which the compiler kept in private memory in the middle of the leaf step) */
+DEV float sphere_hit_root(const DSphere &s, const Ray &r, float a, float t_min, float t_max) {
+    const V3 oc = vsub(r.o, sphere_center(s, r.tm));
+    const float half_b = vdot(oc, r.d);
+    const float c = vlen2(oc) - s.radius * s.radius;
+    const float discriminant = half_b * half_b - a * c;
+    if (discriminant < 0) return -1.0f;
+    const float sqrtd = mort_sqrtf(discriminant);
+    float root = (-half_b - sqrtd) / a;
+    if (root < t_min || t_max < root) {
+        root = (-half_b + sqrtd) / a;
+        if (root < t_min || t_max < root) return -1.0f;
+    }
+    return root;
+}
+
 /* per-ray constants of the own-tree box test: p = b * inv - o * inv */
 struct OwnRay { float ix, iy, iz, mx, my, mz, band, invlen; };
 
@@ -316,8 +334,8 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     const uint32_t p = k ? pb : pa;
                     if (k == 1 && pb == pa) break;
                     const DSphere sp_ = spheres[p];
-                    float t;
-                    if (sphere_hit_t(sp_, ray, ray_a, 0.001f, closest, t)) {
+                    const float t = sphere_hit_root(sp_, ray, ray_a, 0.001f, closest);
+                    if (t != -1.0f) {
                         if (t == closest && best >= 0) flags |= FL_TIE; /* the reference keeps whichever it visits last */
                         closest = t; best = (int)(p | (node << 16));
                     }
