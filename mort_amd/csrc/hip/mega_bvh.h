@@ -524,8 +524,11 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                             a.states[lofs] = st;
                         }
                         /* per-pixel totals straight to the counters (two atomics per pixel; no lane-resident totals) */
-                        atomicAdd(&a.counters[0], (unsigned long long)segments);
-                        atomicAdd(&a.counters[1], (unsigned long long)rng.draws);
+                        if (!PROBE) { /* 32 slots each, picked by workgroup: same-address atomics would queue up behind each other */
+                            const unsigned slot = 32u + 2u * (blockIdx.x & 31u);
+                            atomicAdd(&a.counters[slot], (unsigned long long)segments);
+                            atomicAdd(&a.counters[slot + 1u], (unsigned long long)rng.draws);
+                        }
                         kind = K_NEWPIX;
                     }
                 }

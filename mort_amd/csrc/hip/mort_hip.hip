@@ -466,7 +466,7 @@ extern "C" int mort_hip_init(int device, mort_ctx **out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
-        hipMalloc(&c->d_counters, 32 * sizeof(unsigned long long)) != hipSuccess) {
+        hipMalloc(&c->d_counters, 96 * sizeof(unsigned long long)) != hipSuccess) {
         mort_hip_shutdown(c);
         return MORT_ERR_HIP;
     }
@@ -813,7 +813,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     a.rgba = (uchar4 *)d_rgba; a.accum = (float *)d_accum; a.seg_px = (uint32_t *)c->d_segpx;
     a.counters = c->d_counters;
 
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), s));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s));
     const int tiles = ((W + 7) / 8) * ((a.local_rows + 7) / 8);
     const int waves_per_block = 4;
     const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
@@ -921,7 +921,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
                 HIPCHK(c, hipFuncSetAttribute((const void *)kern_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
                 hipLaunchKernelGGL(kern_probe, dim3(grid), dim3(FB), lds_bytes, s, pa);
                 HIPCHK(c, hipGetLastError());
-                HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 32 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
+                HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
                 c->cost_key = key;
             }
             /* order = argsort(cost, descending); 12.6 k tiles for the headline frame: done on the host */
@@ -951,7 +951,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         HIPCHK(c, hipEventSynchronize(c->ev1));
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        unsigned long long cnt[32] = {0};
+        unsigned long long cnt[96] = {0};
         HIPCHK(c, hipMemcpy(cnt, c->d_counters, sizeof cnt, hipMemcpyDeviceToHost));
 #ifdef MORT_PROFILE_STATES
         if (mode == MORT_MODE_WAVE) {
@@ -987,6 +987,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
 #endif
         std::memset(stats, 0, sizeof *stats);
         stats->seconds = ms * 1e-3;
+        for (int k = 0; k < 32; k++) { cnt[0] += cnt[32 + 2 * k]; cnt[1] += cnt[33 + 2 * k]; } /* BVH megakernel: per-workgroup slots */
         stats->segments = cnt[0];
         stats->rng_draws = cnt[1];
         stats->reference_walks = (use_fast && mode != MORT_MODE_WAVE) ? cnt[3] : 0;
