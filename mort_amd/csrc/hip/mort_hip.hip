@@ -750,8 +750,13 @@ static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera 
     HIPCHK(c, hipGetLastError());
     auto trav = wf_trav<MORT_WF_BLOCK>;
     const size_t stage_bytes = (size_t)(MORT_WF_BLOCK / 64) * 3 * MORT_WF_STAGE * sizeof(unsigned);
-    const size_t ring_off = ((((c->hot_bytes + 15u) & ~15u) + stage_bytes) + 1023) & ~(size_t)1023;
-    const size_t trav_lds = ring_off + (size_t)(MORT_WF_BLOCK / 64) * 4096; /* hot blob | class staging | prefetch rings */
+    /* wf_trav's LDS: the megakernel's image (own tree, leaf records, spheres, ...) | traversal stacks | class staging | prefetch rings */
+    w.trav_src = (const unsigned char *)c->d_fast; w.trav_bytes = c->fast_bytes;
+    w.t_nodes2 = c->f_nodes2; w.t_leaves = c->f_leaves; w.t_spheres = c->f_spheres;
+    w.t_tstack = (c->fast_bytes + 15u) & ~15u;
+    w.t_stage = w.t_tstack + (uint32_t)MORT_OWN_STACK * (uint32_t)MORT_WF_BLOCK * 2u;
+    const size_t ring_off = (((size_t)w.t_stage + stage_bytes) + 1023) & ~(size_t)1023;
+    const size_t trav_lds = ring_off + (size_t)(MORT_WF_BLOCK / 64) * 4096;
     w.off_ring = (uint32_t)ring_off;
     HIPCHK(c, hipFuncSetAttribute((const void *)trav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trav_lds));
     int per_cu = 0;
@@ -825,7 +830,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     const void *fast_kernel_used = nullptr;
     if (mode == MORT_MODE_WAVE) {
         /* the wavefront pipeline covers: one BVH of spheres as the world, no light object */
-        if (!(c->wave_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1))
+        if (!(c->wave_ok && c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1))
             return MORT_ERR_UNSUPPORTED;
     }
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));

@@ -36,7 +36,7 @@
 #ifndef MORT_WAVE_BVH_H
 #define MORT_WAVE_BVH_H
 
-#include "dev_trace.h"
+#include "mega_bvh.h" /* own-tree walk: own_prune, slab_check, reference_walk */
 
 struct __attribute__((aligned(16))) WfRay { float ox, oy, oz, tm; float dx, dy, dz, time0; };
 struct __attribute__((aligned(8))) WfHit { float t; int best; };
@@ -60,6 +60,9 @@ struct WfArgs {
     const unsigned char *hot_src; uint32_t hot_bytes;
     uint32_t off_nodes, off_spheres;
     uint32_t off_ring;        /* LDS offset of the per-wave prefetch rings (wf_trav) */
+    /* wf_trav's own LDS image: the BVH megakernel's (own tree, reference leaf records, spheres, ...) */
+    const unsigned char *trav_src; uint32_t trav_bytes;
+    uint32_t t_nodes2, t_leaves, t_spheres, t_tstack, t_stage;
     int node_first, node_count;
     int n_paths;
     unsigned *q_id[2];        /* front[parity]: path id of each record */
@@ -123,17 +126,19 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
     const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
     {
-        const uint4 *src = (const uint4 *)w.hot_src;
+        const uint4 *src = (const uint4 *)w.trav_src;
         uint4 *dst = (uint4 *)lds;
-        const uint32_t n16 = w.hot_bytes >> 4;
+        const uint32_t n16 = w.trav_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
     }
     const int par = w.parity;
     if (blockIdx.x == 0 && threadIdx.x == 0) w.cnt->front_count[par ^ 1] = 0; /* next front: its last reader was the previous wf_trav */
     __syncthreads();
-    const DBvhNode *nodes = (const DBvhNode *)(lds + w.off_nodes);
-    const DSphere *spheres = (const DSphere *)(lds + w.off_spheres);
-    unsigned *stage = (unsigned *)(lds + ((w.hot_bytes + 15u) & ~15u)) + (threadIdx.x >> 6) * (3 * MORT_WF_STAGE);
+    const DNode2 *nodes2 = (const DNode2 *)(lds + w.t_nodes2);
+    const DBvhNode *leaves = (const DBvhNode *)(lds + w.t_leaves);
+    const DSphere *spheres = (const DSphere *)(lds + w.t_spheres);
+    unsigned short *tstack = (unsigned short *)(lds + w.t_tstack) + threadIdx.x; /* [level * BLOCK] */
+    unsigned *stage = (unsigned *)(lds + w.t_stage) + (threadIdx.x >> 6) * (3 * MORT_WF_STAGE);
     int staged[3] = {0, 0, 0};
     const int lane = threadIdx.x & 63;
     const int node_first = w.node_first, node_end = w.node_first + w.node_count;
@@ -167,10 +172,12 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
     bool have = false;
     unsigned pos = 0;
     float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1, tm = 0;
-    SlabRay sr = slab_ray(0, 0, 0, 0, 0, 1);
+    OwnRay orr; orr.ix = orr.iy = orr.iz = 1; orr.mx = orr.my = orr.mz = 0; orr.band = 0; orr.invlen = 1;
     float ra = 1, closest = 0;
-    int best = -1, node = 0;
-    uint32_t bmat = 0, leaf = 0;
+    int best = -1;          /* sphere | leaf << 16 */
+    uint32_t node = 0;      /* T: own-tree node; L: leaf record */
+    int sp = 0, flags = 0;
+    uint32_t bmat = 0;
 
 #define WF_FLUSH(k) do { \
         if (staged[k] > 0) { \
@@ -207,32 +214,48 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
             int keep;
             do {
                 WPROF(0, __popcll(__ballot(state == W_T)));
-                if (state == W_T) { /* aabb::hit + one move of the threaded walk (aabb.cuh:37-59, objects.cuh:664-723) */
-                    const DBvhNode nd = nodes[node];
-                    const bool miss = !slab_hit(nd, sr, closest);
-                    const int skip = (int)(nd.skip & 0x7fffffffu);
-                    if (miss) node = skip;
-                    else if (nd.skip >> 31) { leaf = nd.prims; node = skip; state = W_L; }
-                    else node = node + 1;
-                    if (state == W_T && node >= node_end) state = W_F;
+                if (state == W_T) { /* both child boxes of one node of the own tree (mega_bvh.h) */
+                    const float4 *np = (const float4 *)(nodes2 + node);
+                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    float te0, te1;
+                    const bool m0 = own_prune(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.z, orr, closest, te0);
+                    const bool m1 = own_prune(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.w, orr, closest, te1);
+                    const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                    const bool both = !m0 && !m1, none = m0 && m1;
+                    const bool first0 = te0 <= te1;
+                    uint32_t next = both ? (first0 ? c0 : c1) : (m0 ? c1 : c0);
+                    if (both) tstack[sp * BLOCK] = (unsigned short)(first0 ? c1 : c0);
+                    sp += both ? 1 : 0;
+                    const bool more = !none || sp > 0;
+                    if (none && sp > 0) { sp--; next = tstack[sp * BLOCK]; }
+                    if (!more) state = W_F;
+                    else { node = next & 0x7fffu; if (next & 0x8000u) state = W_L; }
                 }
                 keep = __popcll(__ballot(state == W_T));
             } while (keep >= MORT_WF_T_KEEP);
             WPROFC(0);
         } else if (pick == W_L) {
             WPROF(1, nL);
-            if (state == W_L) { /* sphere::hit on the leaf's spheres (objects.cuh:60-77,690-692) */
+            if (state == W_L) { /* sphere::hit on the spheres of a reference leaf node (objects.cuh:60-77,690-692) */
+                const uint32_t leaf = leaves[node].prims;
                 const uint32_t pa = leaf & 0x7fffu, pb = (leaf >> 16) & 0x7fffu;
                 Ray r; r.o = mk(ox, oy, oz); r.d = mk(dx, dy, dz); r.tm = tm;
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const uint32_t p = k ? pb : pa;
                     if (k == 1 && pb == pa) break;
-                    const DSphere sp = spheres[p];
-                    float t;
-                    if (sphere_hit_t(sp, r, ra, 0.001f, closest, t)) { closest = t; best = (int)p; bmat = sp.mat; }
+                    const float t = sphere_hit_root(spheres[p], r, ra, 0.001f, closest);
+                    if (t != -1.0f) {
+                        if (t == closest && best >= 0) flags |= FL_TIE;
+                        closest = t; best = (int)(p | (node << 16));
+                    }
                 }
-                state = (node >= node_end) ? W_F : W_T;
+                if (sp > 0) {
+                    sp--;
+                    const uint32_t next = tstack[sp * BLOCK];
+                    node = next & 0x7fffu;
+                    state = (next & 0x8000u) ? W_L : W_T;
+                } else state = W_F;
             }
             WPROFC(1);
         } else {
@@ -241,6 +264,16 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
              * wait for the prefetched batch never covers the stores issued by this step's retire. */
             const bool inF = (state == W_F);
             const bool fin = inF && have;
+            if (fin) { /* is the winner what bvh_node::hit returns?   */
+                Ray r; r.o = mk(ox, oy, oz); r.d = mk(dx, dy, dz); r.tm = tm;
+                bool need_ref = flags != 0;
+                if (!need_ref && best >= 0) need_ref = !slab_check(leaves[best >> 16], r, orr, closest);
+                if (need_ref) {
+                    const RefHit h = reference_walk(w.r.sc.nodes, node_first, node_end, spheres, ox, oy, oz, dx, dy, dz, tm, ra);
+                    best = h.best; closest = h.closest;
+                }
+                if (best >= 0) { best &= 0x7fff; bmat = spheres[best].mat; }
+            }
             const unsigned f_pos = pos;
             const float f_t = closest;
             const int f_best = best;
@@ -268,11 +301,17 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
                             const float4 r0 = ring[cur * 128 + slot], r1 = ring[cur * 128 + 64 + slot];
                             ox = r0.x; oy = r0.y; oz = r0.z; tm = r0.w; dx = r1.x; dy = r1.y; dz = r1.z;
                             pos = A_base + (unsigned)slot;
-                            sr = slab_ray(ox, oy, oz, dx, dy, dz);
                             ra = dx * dx + dy * dy + dz * dz;
-                            closest = __builtin_inff(); best = -1; bmat = 0; node = node_first;
+                            orr.ix = 1.0f / dx; orr.iy = 1.0f / dy; orr.iz = 1.0f / dz;
+                            orr.mx = ox * orr.ix; orr.my = oy * orr.iy; orr.mz = oz * orr.iz;
+                            const float mm = __builtin_fmaxf(__builtin_fmaxf(mort_fabsf(orr.mx), mort_fabsf(orr.my)), mort_fabsf(orr.mz));
+                            orr.band = mm * 4.76837158203125e-07f;
+                            orr.invlen = 1.01f / mort_sqrtf(ra);
+                            const bool ordinary = own_inv_ok(orr.ix) && own_inv_ok(orr.iy) && own_inv_ok(orr.iz) && (mm < 1e30f);
+                            closest = __builtin_inff(); best = -1; bmat = 0; node = 0; sp = 0;
+                            flags = ordinary ? 0 : FL_REF;
                             have = true;
-                            state = (node_first < node_end) ? W_T : W_F;
+                            state = ordinary ? W_T : W_F;
                         }
                         A_head += take; served += take;
                     }
