@@ -104,13 +104,13 @@ extern "C" __global__ void __launch_bounds__(256) wf_init(const WfArgs w) {
 enum { W_T = 0, W_L = 1, W_F = 2, W_DONE = 3 };
 
 #ifndef MORT_WF_TH_F
-#define MORT_WF_TH_F 16
+#define MORT_WF_TH_F 32
 #endif
 #ifndef MORT_WF_TH_L
 #define MORT_WF_TH_L 24
 #endif
 #ifndef MORT_WF_T_KEEP
-#define MORT_WF_T_KEEP 32
+#define MORT_WF_T_KEEP 16
 #endif
 #ifndef MORT_WF_BLOCK
 #define MORT_WF_BLOCK 512
