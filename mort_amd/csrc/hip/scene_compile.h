@@ -266,10 +266,44 @@ struct Compiler {
             const uint32_t pa = kbit | (uint32_t)ids[lo], pb = kbit | (uint32_t)ids[hi - 1];
             prims = pa | (pb << 16);
         } else {
+            /* surface-area heuristic, exhaustive sweep over the three axes (a few thousand primitives at most);
+             * the median of the widest axis when every candidate is degenerate */
             int axis = 0;
             if (cmax[1] - cmin[1] > cmax[axis] - cmin[axis]) axis = 1;
             if (cmax[2] - cmin[2] > cmax[axis] - cmin[axis]) axis = 2;
-            const int mid = lo + n / 2;
+            int mid = lo + n / 2;
+            if (!std::getenv("MORT_ACCEL_MEDIAN")) {
+                double best = 1e300;
+                int bax = -1, bsplit = n / 2;
+                std::vector<int> tmp(n);
+                std::vector<double> ra(n);
+                auto area = [](const Box &b) {
+                    const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
+                    return 2.0 * (x * y + y * z + z * x);
+                };
+                auto uni = [](Box a, const Box &b) { for (int k = 0; k < 3; k++) { a.lo[k] = std::fmin(a.lo[k], b.lo[k]); a.hi[k] = std::fmax(a.hi[k], b.hi[k]); } return a; };
+                for (int ax = 0; ax < 3; ax++) {
+                    std::copy(ids.begin() + lo, ids.begin() + hi, tmp.begin());
+                    std::stable_sort(tmp.begin(), tmp.end(), [&](int a, int b) { return boxes[a].lo[ax] + boxes[a].hi[ax] < boxes[b].lo[ax] + boxes[b].hi[ax]; });
+                    Box r = boxes[tmp[n - 1]]; ra[n - 1] = area(r);
+                    for (int i = n - 2; i >= 0; i--) { r = uni(r, boxes[tmp[i]]); ra[i] = area(r); }
+                    Box l = boxes[tmp[0]];
+                    for (int i = 1; i < n; i++) {
+                        /* keep the tree's depth bounded: no side smaller than an eighth */
+                        if (i >= n / 8 && n - i >= n / 8) {
+                            const double c = area(l) * i + ra[i] * (n - i);
+                            if (c < best) { best = c; bax = ax; bsplit = i; }
+                        }
+                        l = uni(l, boxes[tmp[i]]);
+                    }
+                }
+                if (bax >= 0) {
+                    std::stable_sort(ids.begin() + lo, ids.begin() + hi, [&](int a, int b) { return boxes[a].lo[bax] + boxes[a].hi[bax] < boxes[b].lo[bax] + boxes[b].hi[bax]; });
+                    mid = lo + bsplit;
+                    axis = -1;
+                }
+            }
+            if (axis >= 0)
             std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [&](int a, int b) {
                 const float ca = boxes[a].lo[axis] + boxes[a].hi[axis], cb = boxes[b].lo[axis] + boxes[b].hi[axis];
                 return ca < cb || (ca == cb && a < b);
