@@ -222,6 +222,17 @@ def test_full_geometry_low_spp(gpu_ctx, oracle):
     assert_same(render_gpu(gpu_ctx, world, cam, oracle=oracle), oracle.render(world, cam, nthreads=16))
 
 
+def test_headline_config_matches_oracle_bit_for_bit(gpu_ctx, oracle):
+    """BASELINE config 2 in full (Scene 1 1200x675, 500 spp nominal = 484 effective, depth 20): 392 M samples, 1.02 G
+    segments, every byte of the image, every accumulator bit, every per-pixel segment count and final RNG word
+    against the CPU oracle (about half a minute on the box's 16 host threads)."""
+    world, cam = host.build_scene(1, spp=500)
+    ref = oracle.render(world, cam, nthreads=min(len(os.sched_getaffinity(0)), 32))
+    out = render_gpu(gpu_ctx, world, cam, oracle=oracle)
+    assert out["stats"]["eff_samples"] == 1200 * 675 * 484
+    assert_same(out, ref)
+
+
 def test_headline_config_properties(gpu_ctx, oracle):
     """BASELINE config 2 in full (1200x675, 500 spp nominal = 484 effective): too big for the oracle in a
     test, so size-independent properties: run-to-run determinism, partition invariance of the segment
