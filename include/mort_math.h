@@ -125,6 +125,19 @@ MORT_HD double mort_cos(double x) {
 }
 MORT_HD float mort_sinf(float x) { return (float)mort_sin((double)x); }
 MORT_HD float mort_cosf(float x) { return (float)mort_cos((double)x); }
+/* mort_sinf(x) and mort_cosf(x) at once: the same operations on the same values (one reduction, each kernel
+ * polynomial once), hence the same bits; tests/test_math.py compares them */
+MORT_HD void mort_sincosf(float xf, float *s_out, float *c_out) {
+    const double x = (double)xf;
+    if (!(mort_fabs(x) < 1.0e5)) { *s_out = (float)(x - x); *c_out = (float)(x - x); return; }
+    int q;
+    const double r = mort_rem_pio2(x, &q);
+    const double ks = mort_ksin(r), kc = mort_kcos(r);
+    const double s = (q & 1) ? kc : ks;
+    const double c = (q & 1) ? ks : kc;
+    *s_out = (float)((q & 2) ? -s : s);
+    *c_out = (float)(((q + 1) & 2) ? -c : c);
+}
 
 /* ---- atan on fp64: table of 5 break points + 10-term odd series ---- */
 MORT_HD double mort_atan_pos01(double x) { /* 0 <= x <= 1 */

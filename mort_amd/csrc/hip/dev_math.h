@@ -87,8 +87,10 @@ DEV V3 random_cosine_direction(Rng &s) { /* vec3.cuh:180-189 */
     float r2 = random_float(s);
     float phi = (float)(2 * 3.1415926 * (double)r1);
     float sq = mort_sqrtf(r2);
-    float x = mort_cosf(phi) * sq;
-    float y = mort_sinf(phi) * sq;
+    float sn, cs;
+    mort_sincosf(phi, &sn, &cs); /* == mort_sinf(phi), mort_cosf(phi) */
+    float x = cs * sq;
+    float y = sn * sq;
     float z = mort_sqrtf(1 - r2);
     return mk(x, y, z);
 }

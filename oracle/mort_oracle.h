@@ -57,6 +57,7 @@ void mort_oracle_light_random(const mort_world *w, int type, int idx, const floa
 
 float mort_oracle_sinf(float x);
 float mort_oracle_cosf(float x);
+void mort_oracle_sincosf(float x, float *s, float *c);
 float mort_oracle_acosf(float x);
 float mort_oracle_atan2f(float y, float x);
 float mort_oracle_logf(float x);

@@ -32,6 +32,24 @@ def test_sinf_cosf(oracle):
         assert ok.all(), (name, xs[~ok][:5], got[~ok][:5], want[~ok][:5])
 
 
+def test_sincosf_is_sinf_and_cosf(oracle):
+    """The kernels evaluate sin and cos of random_cosine_direction's angle together (mort_sincosf): bit-identical
+    to the separate functions, including out-of-domain, inf and NaN arguments."""
+    import ctypes as C
+    L = oracle.lib()
+    L.mort_oracle_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.mort_oracle_sincosf.restype = None
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(0, 2 * math.pi, 20000), rng.uniform(-1000, 1000, 5000),
+                         [0.0, -0.0, math.pi, 2 * math.pi, 1e5, -1e5, 99999.99, 3e38, np.inf, -np.inf, np.nan]]).astype(np.float32)
+    s, c = C.c_float(), C.c_float()
+    for x in xs:
+        L.mort_oracle_sincosf(float(x), C.byref(s), C.byref(c))
+        want_s = np.float32(L.mort_oracle_sinf(float(x))); want_c = np.float32(L.mort_oracle_cosf(float(x)))
+        assert np.float32(s.value).view(np.uint32) == want_s.view(np.uint32) or (np.isnan(s.value) and np.isnan(want_s)), x
+        assert np.float32(c.value).view(np.uint32) == want_c.view(np.uint32) or (np.isnan(c.value) and np.isnan(want_c)), x
+
+
 def test_sin_f64(oracle):
     L = oracle.lib()
     rng = np.random.default_rng(2)
