@@ -4,14 +4,13 @@
  *
  * CDNA4 design (each point bit-identical to the reference's arithmetic):
  *
- *  - Scene in LDS.  The whole "hot blob" (threaded BVH nodes, spheres,
- *    material and texture tables, ~46 KB for Scene 1) is copied into LDS once
- *    per workgroup; every traversal step reads one 32-byte node or sphere with
- *    two ds_read_b128.  The reference reads 4 SoA arrays + a 24-byte aabb from
+ *  - Scene in LDS.  The kernel's image of the scene (its own tree as 64-byte two-child nodes, the reference's
+ *    leaf records, spheres, material and texture tables: 48 KB for Scene 1) is copied into LDS once per workgroup;
+ *    a box step reads one node with four ds_read_b128.  The reference reads 4 SoA arrays + a 24-byte aabb from
  *    global memory per node (objects.cuh:728-731).
  *
  *  - Per-lane state machine, wave-level scheduling.  Each lane owns one pixel
- *    and is in one of three states: T (at a BVH node, box test pending),
+ *    and is in one of three states: T (at a tree node, both child boxes to test),
  *    L (inside a leaf, sphere tests pending), S (closest hit known: shade,
  *    scatter, or finish the sample / pixel and start the next ray).  Each
  *    iteration of the wave's loop runs ONE state's code, chosen from the
@@ -20,9 +19,9 @@
  *    (the reference's loop nest, camera.cuh:96-159,187-192, runs every lane in
  *    lockstep with the slowest).
  *
- *  - Dynamic pixels.  Lanes fetch pixels from one atomic counter in 8x8-tile
- *    order (one atomicAdd per wave per refill, lanes ranked by mbcnt), so the
- *    chip stays full until the pool is empty.
+ *  - Dynamic pixels.  Lanes fetch pixels from one atomic counter (one atomicAdd per wave per refill, lanes ranked
+ *    by mbcnt), most expensive 8x8 tiles first, so the chip stays full until the pool is empty; partitions with
+ *    about one pixel per lane spread a fetch over the whole cost order and switch to drain mode (below).
  *
  *  - Own tree, near child first.  The reference walks its median-split tree left-first (objects.cuh:664-723), 41
  *    box tests per segment in Scene 1.  bvh_node::hit returns the closest accepted sphere hit; WHICH one that is
@@ -49,7 +48,7 @@
 
 struct FastArgs {
     RenderArgs r;
-    const unsigned char *hot_src; /* device copy of the hot blob */
+    const unsigned char *hot_src; /* device copy of the kernel's LDS image */
     uint32_t hot_bytes;
     uint32_t off_nodes2, off_leaves, off_spheres, off_lambert, off_metal, off_diel, off_dlight, off_iso, off_solid, off_checker;
     uint32_t off_tstack;  /* LDS offset of the per-lane traversal stacks: [MORT_OWN_STACK][thread] u16 */
