@@ -193,6 +193,94 @@ enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 #define MORT_FAST_BLOCK 768
 #endif
 
+/* ---- a pixel's end and the next pixel's start: once per 484 samples per lane, kept out of line so that their
+ * registers and code stay out of the shade step (like the texture and reference-walk paths above) ---- */
+template <bool PROBE>
+__device__ __attribute__((noinline)) void pixel_write(const FastArgs *fap, float sx, float sy, float sz, int lofs, uint32_t segments,
+                                                      uint32_t draws, uint32_t d, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4) {
+    const FastArgs &fa = *fap;
+    const RenderArgs &a = fa.r;
+    V3 c = vscale(a.pixel_samples_scale, mk(sx, sy, sz)); /* camera.cuh:194-207 */
+    if (c.x != c.x) c.x = 0.0f;
+    if (c.y != c.y) c.y = 0.0f;
+    if (c.z != c.z) c.z = 0.0f;
+    if (fa.tile_cost) {
+        const int lyl = lofs / a.width, xl = lofs - lyl * a.width;
+        atomicAdd(&fa.tile_cost[(lyl >> 3) * fa.tiles_x + (xl >> 3)], segments);
+    }
+    if (!PROBE) {
+        if (a.accum) { a.accum[3 * lofs] = c.x; a.accum[3 * lofs + 1] = c.y; a.accum[3 * lofs + 2] = c.z; }
+        float g[3] = {mort_sqrtf(c.x), mort_sqrtf(c.y), mort_sqrtf(c.z)};
+        unsigned char b[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float v = g[k];
+            if (v < 0.0f) v = 0.0f;
+            if (v > 0.999f) v = 0.999f;
+            b[k] = (unsigned char)mort_f2i(256 * v);
+        }
+        uchar4 out; out.x = b[0]; out.y = b[1]; out.z = b[2]; out.w = 255;
+        a.rgba[lofs] = out;
+        if (a.seg_px) a.seg_px[lofs] = segments;
+        mort_rng_state st;
+        st.d = d; st.v[0] = v0; st.v[1] = v1; st.v[2] = v2; st.v[3] = v3; st.v[4] = v4;
+        st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
+        a.states[lofs] = st;
+        /* per-pixel totals: 32 slots each, picked by workgroup (same-address atomics would queue up behind each other) */
+        const unsigned slot = 32u + 2u * (blockIdx.x & 31u);
+        atomicAdd(&a.counters[slot], (unsigned long long)segments);
+        atomicAdd(&a.counters[slot + 1u], (unsigned long long)draws);
+    }
+}
+struct PixelFetch { int got; int xy, lofs; uint32_t d, v0, v1, v2, v3, v4; };
+/* one atomicAdd per wave per refill; the lanes that call this together take consecutive slots */
+__device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap, unsigned total_q) {
+    const FastArgs &fa = *fap;
+    const RenderArgs &a = fa.r;
+    PixelFetch pf; pf.got = 0; pf.xy = 0; pf.lofs = 0; pf.d = pf.v0 = pf.v1 = pf.v2 = pf.v3 = pf.v4 = 0;
+    bool done = false;
+    while (!done) {
+        const unsigned long long need = __ballot(1);
+        const int cnt = __popcll(need);
+        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+        unsigned base = 0;
+        if (rank == 0) base = atomicAdd(fa.next_q, (unsigned)cnt);
+        base = __shfl(base, __ffsll((long long)need) - 1);
+        const unsigned q = base + (unsigned)rank;
+        if (q >= total_q) break; /* pool empty */
+        /* slot -> (tile rank, pixel of the tile).  A lane's chain advances one segment per round of its
+         * wave's state loop, and a round is slowest when all 64 lanes carry long chains; neighbouring
+         * pixels, on the other hand, keep a wave's rays coherent.  So the 64 slots of one fetch are
+         * 64 >> spread_shift groups of neighbouring pixels, spread evenly over a whole GENERATION of the
+         * cost order (the gen_tiles tiles that the chip's lanes take at once).  Generation g, chunk w,
+         * group u -> tile rank g*G + (w + u*S) mod G, pixel group u of that tile: a rotation per u,
+         * hence a bijection between slots and pixels. */
+        int tslot = (int)(q >> 6), within = (int)(q & 63u);
+        if (fa.gen_tiles > 0) {
+            const int g = tslot / fa.gen_tiles, w = tslot - g * fa.gen_tiles;
+            const int left = fa.tiles_total - g * fa.gen_tiles;
+            const int G = left < fa.gen_tiles ? left : fa.gen_tiles;
+            const int groups = 64 >> fa.spread_shift, u = within >> fa.spread_shift;
+            const int S = G >= groups ? G / groups : 1;
+            tslot = g * fa.gen_tiles + (int)(((unsigned)w + (unsigned)u * (unsigned)S) % (unsigned)G);
+        }
+        const int tile = fa.tile_order ? (int)fa.tile_order[tslot] : tslot;
+        const int tx = tile % fa.tiles_x, ty = tile / fa.tiles_x;
+        const int qx = tx * 8 + (within & 7), qly = ty * 8 + (within >> 3);
+        if (qx < a.width && qly < a.local_rows) {
+            pf.xy = qx | (global_row(qly, a.rank, a.nranks, a.rows_per_block) << 16);
+            pf.lofs = qx + qly * a.width;
+            pf.got = 1;
+            done = true;
+        }
+    }
+    if (pf.got) {
+        const mort_rng_state st = a.states[pf.lofs];
+        pf.d = st.d; pf.v0 = st.v[0]; pf.v1 = st.v[1]; pf.v2 = st.v[2]; pf.v3 = st.v[3]; pf.v4 = st.v[4];
+    }
+    return pf;
+}
+
 /* PROBE = true is the 1-sample cost probe (its own symbol, so profiles keep the frame kernel's durations apart) */
 /* DRAIN = true adds the drain mode below (chain-bound partitions; it costs the throughput-bound frame 5 % in registers) */
 template <int BLOCK, bool PROBE, bool DRAIN = false>
@@ -494,85 +582,19 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
                     if ((s_ij >> 16) < a.sqrt_spp) {
                         kind = K_NEWSAMPLE;
-                    } else { /* camera.cuh:194-207 */
-                        V3 c = vscale(a.pixel_samples_scale, pixel_color);
-                        if (c.x != c.x) c.x = 0.0f;
-                        if (c.y != c.y) c.y = 0.0f;
-                        if (c.z != c.z) c.z = 0.0f;
-                        if (fa.tile_cost) {
-                            const int lyl = lofs / a.width, xl = lofs - lyl * a.width;
-                            atomicAdd(&fa.tile_cost[(lyl >> 3) * fa.tiles_x + (xl >> 3)], segments);
-                        }
-                        if (!PROBE) {
-                            if (a.accum) { a.accum[3 * lofs] = c.x; a.accum[3 * lofs + 1] = c.y; a.accum[3 * lofs + 2] = c.z; }
-                            float g[3] = {mort_sqrtf(c.x), mort_sqrtf(c.y), mort_sqrtf(c.z)};
-                            unsigned char b[3];
-#pragma unroll
-                            for (int k = 0; k < 3; k++) {
-                                float v = g[k];
-                                if (v < 0.0f) v = 0.0f;
-                                if (v > 0.999f) v = 0.999f;
-                                b[k] = (unsigned char)mort_f2i(256 * v);
-                            }
-                            uchar4 out; out.x = b[0]; out.y = b[1]; out.z = b[2]; out.w = 255;
-                            a.rgba[lofs] = out;
-                            if (a.seg_px) a.seg_px[lofs] = segments;
-                            mort_rng_state st;
-                            st.d = rng.d; st.v[0] = rng.v0; st.v[1] = rng.v1; st.v[2] = rng.v2; st.v[3] = rng.v3; st.v[4] = rng.v4;
-                            st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
-                            a.states[lofs] = st;
-                        }
-                        /* per-pixel totals straight to the counters (two atomics per pixel; no lane-resident totals) */
-                        if (!PROBE) { /* 32 slots each, picked by workgroup: same-address atomics would queue up behind each other */
-                            const unsigned slot = 32u + 2u * (blockIdx.x & 31u);
-                            atomicAdd(&a.counters[slot], (unsigned long long)segments);
-                            atomicAdd(&a.counters[slot + 1u], (unsigned long long)rng.draws);
-                        }
+                    } else {
+                        pixel_write<PROBE>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
                         kind = K_NEWPIX;
                     }
                 }
                 REGION("S:newpix");
                 PROFS(5);
                 if (kind == K_NEWPIX) {
-                    /* one atomicAdd per wave per refill; lanes take consecutive slots in 8x8-tile order */
-                    bool got = false;
-                    while (!got) {
-                        const unsigned long long need = __ballot(1);
-                        const int cnt = __popcll(need);
-                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
-                        unsigned base = 0;
-                        if (rank == 0) base = atomicAdd(fa.next_q, (unsigned)cnt);
-                        base = __shfl(base, __ffsll((long long)need) - 1);
-                        const unsigned q = base + (unsigned)rank;
-                        if (q >= total_q) { state = ST_DONE; got = true; break; }
-                        /* slot -> (tile rank, pixel of the tile).  A lane's chain advances one segment per round of its
-                         * wave's state loop, and a round is slowest when all 64 lanes carry long chains; neighbouring
-                         * pixels, on the other hand, keep a wave's rays coherent.  So the 64 slots of one fetch are
-                         * 64 >> spread_shift groups of neighbouring pixels, spread evenly over a whole GENERATION of the
-                         * cost order (the gen_tiles tiles that the chip's lanes take at once).  Generation g, chunk w,
-                         * group u -> tile rank g*G + (w + u*S) mod G, pixel group u of that tile: a rotation per u,
-                         * hence a bijection between slots and pixels. */
-                        int tslot = (int)(q >> 6), within = (int)(q & 63u);
-                        if (fa.gen_tiles > 0) {
-                            const int g = tslot / fa.gen_tiles, w = tslot - g * fa.gen_tiles;
-                            const int left = fa.tiles_total - g * fa.gen_tiles;
-                            const int G = left < fa.gen_tiles ? left : fa.gen_tiles;
-                            const int groups = 64 >> fa.spread_shift, u = within >> fa.spread_shift;
-                            const int S = G >= groups ? G / groups : 1;
-                            tslot = g * fa.gen_tiles + (int)(((unsigned)w + (unsigned)u * (unsigned)S) % (unsigned)G);
-                        }
-                        const int tile = fa.tile_order ? (int)fa.tile_order[tslot] : tslot;
-                        const int tx = tile % fa.tiles_x, ty = tile / fa.tiles_x;
-                        const int qx = tx * 8 + (within & 7), qly = ty * 8 + (within >> 3);
-                        if (qx < a.width && qly < a.local_rows) {
-                            xy = qx | (global_row(qly, a.rank, a.nranks, a.rows_per_block) << 16);
-                            lofs = qx + qly * a.width;
-                            got = true;
-                        }
-                    }
-                    if (state != ST_DONE) {
-                        const mort_rng_state st = a.states[lofs];
-                        rng.d = st.d; rng.v0 = st.v[0]; rng.v1 = st.v[1]; rng.v2 = st.v[2]; rng.v3 = st.v[3]; rng.v4 = st.v[4];
+                    const PixelFetch pf = pixel_fetch(&fa, total_q);
+                    if (!pf.got) state = ST_DONE;
+                    else {
+                        xy = pf.xy; lofs = pf.lofs;
+                        rng.d = pf.d; rng.v0 = pf.v0; rng.v1 = pf.v1; rng.v2 = pf.v2; rng.v3 = pf.v3; rng.v4 = pf.v4;
                         rng.draws = 0;
                         pixel_color = mk(0, 0, 0);
                         s_ij = 0; segments = 0;
