@@ -206,6 +206,31 @@ def test_scheduling_choices_do_not_reach_the_pixels(gpu_ctx, oracle, monkeypatch
     assert_same(out2, ref2)
 
 
+@pytest.mark.parametrize("sid", [1, 10])
+def test_other_viewpoints(gpu_ctx, oracle, sid):
+    """The built-in cameras look at the BVH scenes from one side only.  Other ray populations for the own-tree walk
+    (DESIGN.md 4.2): cameras inside the sphere field, at ground level, under the ground, looking straight up / down /
+    along an axis (direction components that are exactly zero take the reference walk), zoomed far out, with and
+    without defocus -- each against the oracle, bit for bit."""
+    from mort_amd.host import lib as host_lib
+    import ctypes as C
+    world, cam = host.build_scene(sid, width=120, spp=4)
+    rng = np.random.default_rng(7 + sid)
+    views = [((0.5, 0.3, 0.5), (3.0, 0.3, 0.2)), ((0.0, 0.21, 2.0), (0.0, 0.21, -5.0)), ((2.0, -3.0, 1.0), (0.0, 1.0, 0.0)),
+             ((0.0, 30.0, 0.0), (0.0, 0.0, 0.001)), ((0.0, 0.5, 0.0), (0.0, 10.0, 0.0001)), ((5.0, 1.0, 0.0), (-5.0, 1.0, 0.0)),
+             ((300.0, 120.0, 200.0), (0.0, 0.0, 0.0)), ((0.0, 1.0, 0.0), (4.0, 1.0, 0.0))]
+    views += [(tuple(rng.uniform(-9, 9, 3) * (1, 0.2, 1) + (0, 0.5, 0)), tuple(rng.uniform(-6, 6, 3) * (1, 0.1, 1))) for _ in range(4)]
+    for k, (frm, at) in enumerate(views):
+        for i in range(3):
+            cam.lookfrom.e[i] = frm[i]; cam.lookat.e[i] = at[i]
+        cam.defocus_angle = 0.0 if k % 2 else 0.6
+        cam.vfov = 20 if k % 3 else 70
+        host_lib().mort_camera_initialize(C.byref(cam))
+        ref = oracle.render(world, cam, nthreads=8)
+        out = render_gpu(gpu_ctx, world, cam, oracle=oracle)
+        assert_same(out, ref)
+
+
 def test_reference_walk_is_rare_and_counted(gpu_ctx, oracle):
     """The BVH megakernel re-traces a ray with the reference's own walk when it cannot prove its winner
     (DESIGN.md 4.2): a handful per million segments, reported in the stats."""
