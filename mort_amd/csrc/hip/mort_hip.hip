@@ -358,9 +358,6 @@ struct mort_ctx {
     void *d_rgba = nullptr, *d_accum = nullptr, *d_segpx = nullptr;
     size_t rgba_cap = 0, accum_cap = 0, segpx_cap = 0;
     unsigned long long *d_counters = nullptr; /* [0] segments, [1] rng draws, [2] work counter */
-    /* fast (BVH-in-LDS) kernel: offsets of the tables inside the hot blob */
-    uint32_t off_nodes = 0, off_spheres = 0, off_lambert = 0, off_metal = 0, off_diel = 0, off_dlight = 0, off_iso = 0,
-             off_solid = 0, off_checker = 0, hot_bytes = 0;
     bool wave_ok = false; /* wavefront mode: one BVH over spheres as the whole world, hot blob fits LDS */
     /* BVH megakernel: its own LDS image (own tree, reference leaf records, spheres, material / texture tables) */
     void *d_fast = nullptr;
@@ -598,11 +595,8 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     c->list_types = o.list_types; c->list_idxs = o.list_idxs;
     for (int i = 0; i < MORT_NUM_HITTABLE_LIST; i++) { c->list_first[i] = o.list_first[i]; c->list_count[i] = o.list_count[i]; }
     c->n_wspheres = (int)o.wspheres.size(); c->n_wquads = (int)o.wquads.size(); c->n_lists = w->objs.num_hittable_list;
-    c->off_nodes = (uint32_t)o_nodes; c->off_spheres = (uint32_t)o_sph; c->off_lambert = (uint32_t)o_lamb;
-    c->off_metal = (uint32_t)o_metal; c->off_diel = (uint32_t)o_diel; c->off_dlight = (uint32_t)o_dl; c->off_iso = (uint32_t)o_iso;
-    c->off_solid = (uint32_t)o_solid; c->off_checker = (uint32_t)o_chk; c->hot_bytes = (uint32_t)hot_bytes;
     /* the LDS kernels handle: one BVH over spheres as the whole world */
-    c->wave_ok = (o.items.size() == 1 && o.items[0].kind == ITEM_BVH && o.quads.empty() && hot_bytes <= 64 * 1024);
+    c->wave_ok = (o.items.size() == 1 && o.items[0].kind == ITEM_BVH && o.quads.empty());
     c->fast_ok = false;
     if (c->d_fast) { hipFree(c->d_fast); c->d_fast = nullptr; }
     if (c->wave_ok && !o.own_nodes.empty()) {
@@ -734,8 +728,6 @@ static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera 
     WfArgs w;
     std::memset(&w, 0, sizeof w);
     w.r = a;
-    w.hot_src = (const unsigned char *)c->d_scene; w.hot_bytes = c->hot_bytes;
-    w.off_nodes = c->off_nodes; w.off_spheres = c->off_spheres;
     w.node_first = 0; w.node_count = c->sc.n_nodes;
     w.n_paths = (int)N;
     w.q_ray[0] = (WfRay *)(base + o_ray0); w.q_ray[1] = (WfRay *)(base + o_ray1);
@@ -837,7 +829,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     if (blocks > 0 && mode == MORT_MODE_WAVE) {
         int st_w = render_wavefront(c, a, cam, s);
         if (st_w != MORT_OK) return st_w;
-        lds_bytes_used = (int)c->hot_bytes;
+        lds_bytes_used = (int)c->fast_bytes;
     } else if (blocks > 0 && use_fast) {
         FastArgs fa;
         std::memset(&fa, 0, sizeof fa);

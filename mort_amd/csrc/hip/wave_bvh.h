@@ -57,8 +57,6 @@ struct WfCounters {
 
 struct WfArgs {
     RenderArgs r;
-    const unsigned char *hot_src; uint32_t hot_bytes;
-    uint32_t off_nodes, off_spheres;
     uint32_t off_ring;        /* LDS offset of the per-wave prefetch rings (wf_trav) */
     /* wf_trav's own LDS image: the BVH megakernel's (own tree, reference leaf records, spheres, ...) */
     const unsigned char *trav_src; uint32_t trav_bytes;
