@@ -115,7 +115,11 @@ DEV V3 light_random(const DScene &sc, int type, int idx, V3 origin, Rng &rng) {
  * pushed emission is always (0,0,0): only diffuse_light emits and it never scatters. */
 struct StackEntry { float kx, ky, kz, rp; };
 
-extern "C" __global__ void __launch_bounds__(256)
+/* 3 waves per SIMD: without the bound the compiler takes 172 VGPRs, two over the limit for three */
+#ifndef MORT_GENERIC_WAVES
+#define MORT_GENERIC_WAVES 3
+#endif
+extern "C" __global__ void __launch_bounds__(256, MORT_GENERIC_WAVES)
 mega_kernel(const RenderArgs a) {
     const DScene &sc = a.sc;
     const int lane = threadIdx.x & 63;
