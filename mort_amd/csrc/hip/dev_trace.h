@@ -427,7 +427,7 @@ DEV float perlin_noise(const float *nt, V3 p) { /* textures.cuh:174-196,232-250 
             }
     return (float)accum;
 }
-DEV V3 noise_value(const DScene &sc, int idx, V3 p) { /* textures.cuh:198-202,252-265 */
+__device__ __attribute__((noinline)) V3 noise_value(const DScene &sc, int idx, V3 p) { /* out of line: 7 x 8 gradient fetches, fp64 accumulators */ /* textures.cuh:198-202,252-265 */
     const float *nt = sc.noise + (size_t)idx * (sizeof(mort_noise_texture) / 4);
     const float scale = nt[3 * MORT_POINT_COUNT + 3 * MORT_POINT_COUNT];
     const V3 s = vscale(scale, p);
@@ -443,7 +443,7 @@ DEV V3 noise_value(const DScene &sc, int idx, V3 p) { /* textures.cuh:198-202,25
     const V3 half = vscale(0.5f, mk(1, 1, 1));
     return vscale((float)(1 + mort_sin((double)s.z + 10.0 * (double)turb)), half);
 }
-DEV V3 image_value(const DScene &sc, int idx, float u, float v) { /* textures.cuh:129-146 */
+__device__ __attribute__((noinline)) V3 image_value(const DScene &sc, int idx, float u, float v) { /* textures.cuh:129-146 */
     const DImage im = sc.image[idx];
     if (im.height <= 0) return mk(0, 1, 1);
     u = clamp01(u);
