@@ -150,7 +150,7 @@ def main():
         # only quoted when this run is the profiled configuration
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "v9_pmc_hbm.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "v10_pmc_hbm.json")))
             cfg = pm["config"]
             if (args.scene, W, H, args.spp, world_size) == (cfg["scene"], cfg["width"], cfg["height"], cfg["spp"], cfg["gpus"]):
                 traffic = pm["traffic_bytes_per_launch"]
@@ -169,11 +169,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "mega_bvh_kernel" if st["scene_in_lds"] else "mega_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "traffic_source": "profiles/r1/v9_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
+                         "traffic_source": "profiles/r1/v10_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
                          "note": "megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
                                  "so the HBM fraction is tiny; the binding resource is VALU issue (DESIGN.md 4)",
                          "valu_issue_frac": 0.92 if traffic else None,
-                         "valu_issue_source": "profiles/r1/v9_pmc_sq_summary.csv: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32)"
+                         "valu_issue_source": "profiles/r1/v10_pmc_sq_summary.csv: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32)"
                                               if traffic else None},
             "kernel": {"segments_per_frame": st["segments"], "segments_per_s": st["segments"] / st["seconds"],
                        "hip_event_seconds": st["seconds"], "vgprs": st["kernel_vgprs"], "lds_bytes": st["kernel_lds_bytes"]},
