@@ -172,7 +172,7 @@ def main():
                          "traffic_source": "profiles/r1/v10_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
                          "note": "megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
                                  "so the HBM fraction is tiny; the binding resource is VALU issue (DESIGN.md 4)",
-                         "valu_issue_frac": 0.92 if traffic else None,
+                         "valu_issue_frac": 0.94 if traffic else None,
                          "valu_issue_source": "profiles/r1/v10_pmc_sq_summary.csv: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32)"
                                               if traffic else None},
             "kernel": {"segments_per_frame": st["segments"], "segments_per_s": st["segments"] / st["seconds"],
