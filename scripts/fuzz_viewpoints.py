@@ -1,5 +1,6 @@
 """One-off hunt for rays on which the BVH megakernel and the oracle disagree: random cameras (position, target, field of
-view, defocus, time) on the BVH scenes, bit-for-bit comparison.  usage: fuzz_viewpoints.py [cases] [seed]"""
+view, defocus, time) on the BVH scenes (or, with a third argument "all", on all ten scenes: generic kernel, this build's
+trees over long runs), bit-for-bit comparison.  usage: fuzz_viewpoints.py [cases] [seed] [all]"""
 import ctypes as C
 import os
 import sys
@@ -16,11 +17,13 @@ ctx = hip.Context(0)
 bad = 0
 walks = segs = 0
 for k in range(cases):
-    sid = 1 if k % 4 else 10
-    world, cam = host.build_scene(sid, width=int(rng.integers(90, 260)), spp=int(rng.choice([4, 9, 16])), depth=int(rng.choice([3, 8, 20, 50])))
-    frm = rng.uniform(-12, 12, 3) * (1, 0.25, 1) + (0, 0.6, 0)
+    sid = (1 if k % 4 else 10) if len(sys.argv) <= 3 else int(rng.integers(1, 11))
+    big = sid in (8, 9)
+    world, cam = host.build_scene(sid, width=int(rng.integers(40, 90) if big else rng.integers(90, 260)), spp=int(rng.choice([4, 9]) if big else rng.choice([4, 9, 16])), depth=int(rng.choice([3, 8, 20, 50])))
+    scale = {5: 1.0, 6: 45.0, 7: 45.0, 8: 45.0, 9: 45.0}.get(sid, 1.0)
+    frm = (rng.uniform(-12, 12, 3) * (1, 0.25, 1) + (0, 0.6, 0)) * scale + ((278, 278, -300) if scale > 1 else (0, 0, 0))
     if k % 5 == 0: frm[1] = rng.uniform(-2, 0.19)      # under or at ground level
-    at = rng.uniform(-6, 6, 3) * (1, 0.15, 1)
+    at = rng.uniform(-6, 6, 3) * (1, 0.15, 1) * scale + ((278, 278, 278) if scale > 1 else (0, 0, 0))
     for i in range(3):
         cam.lookfrom.e[i] = float(frm[i]); cam.lookat.e[i] = float(at[i])
     cam.vfov = int(rng.choice([10, 20, 40, 90, 120]))
