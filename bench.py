@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--rows-per-block", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")
+    ap.add_argument("--mode", choices=["mega", "wave"], default="mega",
+                    help="mega: the headline megakernel; wave: the wavefront (HBM-streaming) form of the same path")
     args = ap.parse_args()
 
     import torch
@@ -99,6 +101,7 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ev_pairs = []
+    mode = hip.MODE_WAVE if args.mode == "wave" else hip.MODE_MEGA
 
     def step(record):
         e0 = e1 = None
@@ -107,7 +110,7 @@ def main():
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record(stream)
         # the kernel is launched on torch's current stream, so these events bracket it
-        ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, sync=False)
+        ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, mode=mode, sync=False)
         if record:
             e1.record(stream)
             ev_pairs.append((e0, e1))
@@ -137,7 +140,7 @@ def main():
     elapsed_max = float(t.item())
 
     # one more frame through the blocking entry to read the library's own counters/HIP-event time
-    st = ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, sync=True)
+    st = ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, mode=mode, sync=True)
 
     if rank == 0:
         samples_per_step = W * H * eff
@@ -145,6 +148,8 @@ def main():
         avg_kernel_s = (sum(kernel_ms) / max(len(kernel_ms), 1)) * 1e-3
         pixels_launch = W * lr
         algo_bytes = 100 * pixels_launch  # 48 B state in + 48 B out + 4 B uchar4 per pixel; 0 B per segment
+        if args.mode == "wave":
+            algo_bytes = int(st["algorithmic_hbm_bytes"])  # + 240 B per segment of front / hit / pixel / stack records (wave_bvh.h)
         achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         # HBM traffic from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process);
         # only quoted when this run is the profiled configuration
@@ -152,7 +157,7 @@ def main():
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "v10_pmc_hbm.json")))
             cfg = pm["config"]
-            if (args.scene, W, H, args.spp, world_size) == (cfg["scene"], cfg["width"], cfg["height"], cfg["spp"], cfg["gpus"]):
+            if args.mode == "mega" and (args.scene, W, H, args.spp, world_size) == (cfg["scene"], cfg["width"], cfg["height"], cfg["spp"], cfg["gpus"]):
                 traffic = pm["traffic_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -162,16 +167,19 @@ def main():
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Scene {args.scene} (random-spheres cover) {W}x{H}, {args.spp} spp nominal = {eff} effective, "
-                                   f"depth {cam.bounce_limit}, megakernel, seed 69420, host LCG scene",
-                       "mode": "mega", "partition": f"rows/{args.rows_per_block} interleaved over {world_size} rank(s)",
+                                   f"depth {cam.bounce_limit}, {'megakernel' if args.mode == 'mega' else 'wavefront kernels'}, seed 69420, host LCG scene",
+                       "mode": args.mode, "partition": f"rows/{args.rows_per_block} interleaved over {world_size} rank(s)",
                        "nominal_msamples_per_s": W * H * args.spp * args.steps / elapsed_max / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "mega_bvh_kernel" if st["scene_in_lds"] else "mega_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": ("wf_trav + wf_shade (per front)" if args.mode == "wave" else "mega_bvh_kernel" if st["scene_in_lds"] else "mega_kernel"),
+                         "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "traffic_source": "profiles/r1/v10_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
-                         "note": "megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
-                                 "so the HBM fraction is tiny; the binding resource is VALU issue (DESIGN.md 4)",
+                         "note": ("megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
+                                  "so the HBM fraction is tiny; the binding resource is VALU issue (DESIGN.md 4)") if args.mode == "mega" else
+                                 ("wavefront form: 100 B per pixel + 240 B per segment of front / hit / pixel / stack records; bound by "
+                                  "front granularity (one segment of every live pixel per launch pair), not by HBM (DESIGN.md 4)"),
                          "valu_issue_frac": 0.94 if traffic else None,
                          "valu_issue_source": "profiles/r1/v10_pmc_sq_summary.csv: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32)"
                                               if traffic else None},
