@@ -33,10 +33,17 @@ $(LIBDIR)/libmort_host.so: $(HOST_SRC) $(wildcard include/*.h) mort_amd/csrc/hos
 	@mkdir -p $(LIBDIR)
 	$(CC) $(CFLAGS) -shared -o $@ $(HOST_SRC) -lm
 
+# one object per .hip translation unit (no relocatable device code: every kernel lives in the TU that launches it)
+OBJDIR := build/hip
+HIP_OBJ := $(patsubst mort_amd/csrc/hip/%.hip,$(OBJDIR)/%.o,$(HIP_SRC))
+
 hip: $(LIBDIR)/libmort_hip.so
-$(LIBDIR)/libmort_hip.so: $(HIP_SRC) $(HIP_HDR)
+$(OBJDIR)/%.o: mort_amd/csrc/hip/%.hip $(HIP_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(LIBDIR)/libmort_hip.so: $(HIP_OBJ)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-rdc -shared -o $@ $(HIP_OBJ) -lpthread -ldl
 
 oracle:
 	$(MAKE) -C oracle
@@ -48,5 +55,5 @@ $(BINDIR)/mort: mort_amd/csrc/cli/mort.c $(LIBDIR)/libmort_host.so $(LIBDIR)/lib
 	    -Wl,-rpath,'$$ORIGIN/../lib' -lm -lpthread
 
 clean:
-	rm -rf $(LIBDIR) $(BINDIR)
+	rm -rf $(LIBDIR) $(BINDIR) $(OBJDIR)
 	$(MAKE) -C oracle clean

@@ -26,26 +26,73 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SCENE_NAMES = {1: "random-spheres cover", 2: "two checker spheres", 3: "earth", 4: "two Perlin spheres", 5: "quads",
+               6: "Cornell box, emissive light + MIS", 7: "Cornell smoke", 8: "book-2 final scene", 9: "book-2 final scene, low settings",
+               10: "out-of-order spheres"}
 
 
-def cpu_baseline(spp_sample, threads):
-    """Oracle (CPU restatement, oracle/) timed on this box's host cores on a bounded sample of the
-    same workload: Scene 1 at the full 1200x675 geometry, reduced spp."""
+def _oracle_run(scene, width, spp, depth, aspect, threads):
     from mort_amd import host
     from tests import oracle_lib as O
-    world, cam = host.build_scene(1, spp=spp_sample)
+    world, cam = host.build_scene(scene, width=width, spp=spp, depth=depth, aspect=aspect)
     states = O.seed_states(69420, cam.image_width, cam.image_height)
     t0 = time.perf_counter()
     r = O.render(world, cam, states=states, nthreads=threads, want_accum=False, want_segments=False)
     dt = time.perf_counter() - t0
     eff = host.effective_spp(cam)
     samples = cam.image_width * cam.image_height * eff
+    return {"msamples_per_s": samples / dt / 1e6, "seconds": dt, "segments": r["segments"], "samples": samples,
+            "geometry": f"{cam.image_width}x{cam.image_height}", "eff_spp": eff, "depth": cam.bounce_limit, "threads": threads}
+
+
+def cpu_baseline(args, threads):
+    """Oracle (CPU restatement, oracle/) timed on this box's host cores: a bounded sample of the
+    benchmarked workload (full geometry, reduced spp) on all threads and on one thread, and BASELINE config 1
+    (Scene 1 200x112, 4 spp) in full on one thread."""
+    a = _oracle_run(args.scene, args.width, args.cpu_spp, args.depth, args.aspect, threads)
+    one = _oracle_run(args.scene, args.width, 1, args.depth, args.aspect, 1)
+    c1 = _oracle_run(1, 200, 4, None, None, 1)
     return {
-        "value": samples / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-        "sample": f"Scene 1 1200x675 at {spp_sample} spp ({eff} effective), depth 20: {samples} samples, "
-                  f"{r['segments']} segments in {dt:.2f} s on {threads} host threads (C oracle, oracle/mort_oracle.c)",
-        "seconds": dt, "segments": r["segments"],
+        "value": a["msamples_per_s"], "unit": "Msamples/s", "cores": threads, "kind": "port",
+        "sample": f"Scene {args.scene} {a['geometry']} at {args.cpu_spp} spp ({a['eff_spp']} effective), depth {a['depth']}: "
+                  f"{a['samples']} samples, {a['segments']} segments in {a['seconds']:.2f} s on {threads} host threads "
+                  f"(C oracle, oracle/mort_oracle.c)",
+        "seconds": a["seconds"], "segments": a["segments"],
+        "one_thread": {"value": one["msamples_per_s"], "unit": "Msamples/s", "cores": 1,
+                       "sample": f"same geometry at 1 spp: {one['samples']} samples in {one['seconds']:.2f} s"},
+        "config1_full": {"value": c1["msamples_per_s"], "unit": "Msamples/s", "cores": 1,
+                         "sample": f"BASELINE config 1 in full: Scene 1 {c1['geometry']}, 4 spp, depth {c1['depth']}: "
+                                   f"{c1['samples']} samples, {c1['segments']} segments in {c1['seconds']:.3f} s"},
     }
+
+
+def profile_figures(tag, kernel_substr):
+    """Counter figures of the profiled configuration, computed from the rocprofv3 summaries committed under
+    profiles/ (rocprofv3 cannot run inside this process): HBM traffic per launch, VALU issue fraction and VALU
+    lane occupancy of the dominant kernel."""
+    import csv
+    out = {"traffic": None, "config": None}
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", tag + "_pmc_hbm.json")))
+        out["traffic"] = pm["traffic_bytes_per_launch"]
+        out["config"] = pm["config"]
+        out["traffic_source"] = f"profiles/{tag}_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)"
+    except Exception:
+        pass
+    try:
+        c = {}
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_pmc_sq_summary.csv"))):
+            if kernel_substr in r["kernel"] and "true" not in r["kernel"].split("<")[-1].split()[1:2]:
+                c.setdefault(r["counter"], float(r["per_dispatch"]))
+        # 1024 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines; a VALU instruction holds its SIMD for 4 cycles
+        out["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0)
+        out["valu_lane_occupancy"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)
+        out["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
+        out["valu_source"] = (f"profiles/{tag}_pmc_sq_summary.csv: issue = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32); "
+                              "lane occupancy = SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64)")
+    except Exception:
+        pass
+    return out
 
 
 def main():
@@ -55,7 +102,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp", type=int, default=500)
     ap.add_argument("--width", type=int, default=1200)
-    ap.add_argument("--scene", type=int, default=1)
+    ap.add_argument("--scene", type=int, default=1, help="reference scene id 1..10 (default 1 = the headline workload)")
+    ap.add_argument("--depth", type=int, default=None, help="bounce limit override")
+    ap.add_argument("--aspect", type=float, default=None, help="aspect ratio override")
+    ap.add_argument("--profile-tag", default="r2/headline", help="profiles/<tag>_pmc_*.{json,csv}: counter figures quoted when the run is the profiled configuration")
     ap.add_argument("--rows-per-block", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")
@@ -84,7 +134,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     # ---- scene, upload, seed (outside the timed region) ----
-    world, cam = host.build_scene(args.scene, width=args.width, spp=args.spp)
+    world, cam = host.build_scene(args.scene, width=args.width, spp=args.spp, depth=args.depth, aspect=args.aspect)
     W, H = cam.image_width, cam.image_height
     eff = host.effective_spp(cam)
     ctx = hip.Context(local_rank)
@@ -151,44 +201,41 @@ def main():
         if args.mode == "wave":
             algo_bytes = int(st["algorithmic_hbm_bytes"])  # + 240 B per segment of front / hit / pixel / stack records (wave_bvh.h)
         achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
-        # HBM traffic from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process);
-        # only quoted when this run is the profiled configuration
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1", "v10_pmc_hbm.json")))
-            cfg = pm["config"]
-            if args.mode == "mega" and (args.scene, W, H, args.spp, world_size) == (cfg["scene"], cfg["width"], cfg["height"], cfg["spp"], cfg["gpus"]):
-                traffic = pm["traffic_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        kernel_name = ("wf_trav + wf_shade (per front)" if args.mode == "wave" else st["kernel_name"])
+        # counter figures from the PMC passes committed under profiles/, quoted only when this run is the profiled configuration
+        pf = profile_figures(args.profile_tag, "wf_" if args.mode == "wave" else kernel_name.split("<")[0])
+        cfg = pf.get("config") or {}
+        same = (args.scene, W, args.spp, world_size, args.mode) == (cfg.get("scene"), cfg.get("width"), cfg.get("spp"), cfg.get("gpus"), cfg.get("mode", "mega"))
+        if not same:
+            pf = {"traffic": None}
+        traffic = pf.get("traffic")
         out = {
-            "metric": "Msamples/sec (width x height x spp/s), Scene 1 1200x675",
+            "metric": f"Msamples/sec (width x height x spp/s), Scene {args.scene} {W}x{H}",
             "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"Scene {args.scene} (random-spheres cover) {W}x{H}, {args.spp} spp nominal = {eff} effective, "
+            "config": {"workload": f"Scene {args.scene} ({SCENE_NAMES.get(args.scene, '?')}) {W}x{H}, {args.spp} spp nominal = {eff} effective, "
                                    f"depth {cam.bounce_limit}, {'megakernel' if args.mode == 'mega' else 'wavefront kernels'}, seed 69420, host LCG scene",
                        "mode": args.mode, "partition": f"rows/{args.rows_per_block} interleaved over {world_size} rank(s)",
                        "nominal_msamples_per_s": W * H * args.spp * args.steps / elapsed_max / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("wf_trav + wf_shade (per front)" if args.mode == "wave" else "mega_bvh_kernel" if st["scene_in_lds"] else "mega_kernel"),
+                         "kernel": kernel_name,
                          "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "traffic_source": "profiles/r1/v10_pmc_hbm.json (FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
+                         "traffic_source": pf.get("traffic_source"),
                          "note": ("megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
                                   "so the HBM fraction is tiny; the binding resource is VALU issue (DESIGN.md 4)") if args.mode == "mega" else
                                  ("wavefront form: 100 B per pixel + 240 B per segment of front / hit / pixel / stack records; bound by "
                                   "front granularity (one segment of every live pixel per launch pair), not by HBM (DESIGN.md 4)"),
-                         "valu_issue_frac": 0.94 if traffic else None,
-                         "valu_issue_source": "profiles/r1/v10_pmc_sq_summary.csv: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32)"
-                                              if traffic else None},
+                         "valu_issue_frac": pf.get("valu_issue_frac"), "valu_lane_occupancy": pf.get("valu_lane_occupancy"),
+                         "valu_insts_per_launch": pf.get("valu_insts_per_launch"), "valu_source": pf.get("valu_source")},
             "kernel": {"segments_per_frame": st["segments"], "segments_per_s": st["segments"] / st["seconds"],
                        "hip_event_seconds": st["seconds"], "vgprs": st["kernel_vgprs"], "lds_bytes": st["kernel_lds_bytes"]},
         }
         if world_size == 1 and args.cpu_spp > 0:
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)  # 16 = one GPU's CPU share
-            out["cpu_baseline"] = cpu_baseline(args.cpu_spp, threads)
+            out["cpu_baseline"] = cpu_baseline(args, threads)
         print(json.dumps(out), flush=True)
 
     ctx.close()

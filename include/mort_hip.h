@@ -71,6 +71,7 @@ typedef struct mort_stats {
     int local_rows;          /* rows owned under the partition */
     int kernel_vgprs, kernel_lds_bytes; /* launch facts, for reports */
     uint64_t reference_walks; /* BVH megakernel: segments re-traced with the reference's own walk */
+    char kernel_name[64];    /* dominant kernel of this render as rocprofv3 names it (template arguments included) */
 } mort_stats;
 
 const char *mort_hip_strerror(int status);

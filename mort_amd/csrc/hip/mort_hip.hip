@@ -25,95 +25,13 @@
 #include <vector>
 
 #include "mort_hip.h"
-#include "dev_trace.h"
+#include "dev_render.h"
 #include "scene_compile.h"
+#include "mort_internal.h"
 
 #pragma clang fp contract(off)
 
 /* ====================================================================== device */
-
-struct RenderArgs {
-    DScene sc;
-    /* camera (camera.cuh:13-45) */
-    int width, height;
-    int sqrt_spp, bounce_limit;
-    float recip_sqrt_spp, pixel_samples_scale;
-    V3 background, center, pixel00, du, dv, defocus_u, defocus_v;
-    float defocus_angle;
-    int light_type, light_idx;
-    /* partition: this launch owns row blocks rank, rank + nranks, ... */
-    int rank, nranks, rows_per_block, local_rows;
-    /* buffers (packed owned rows) */
-    mort_rng_state *states;
-    uchar4 *rgba;
-    float *accum;          /* may be null */
-    uint32_t *seg_px;      /* may be null */
-    unsigned long long *counters; /* [0] segments, [1] rng draws */
-};
-
-DEV int global_row(int ly, int rank, int nranks, int rpb) {
-    const int lb = ly / rpb, within = ly - lb * rpb;
-    return (lb * nranks + rank) * rpb + within;
-}
-
-/* ---- Camera::get_ray (camera.cuh:210-242) ---- */
-DEV Ray get_ray(const RenderArgs &a, int x, int y, Rng &rng, int s_i, int s_j) {
-    const double px = (double)(((float)s_i + random_float(rng)) * a.recip_sqrt_spp) - 0.5;
-    const double py = (double)(((float)s_j + random_float(rng)) * a.recip_sqrt_spp) - 0.5;
-    const float ox = (float)px, oy = (float)py;
-    const V3 pixel_sample = vadd(vadd(a.pixel00, vscale((float)((double)x + (double)ox), a.du)),
-                                 vscale((float)((double)y + (double)oy), a.dv));
-    V3 origin;
-    if (a.defocus_angle <= 0) {
-        origin = a.center;
-    } else {
-        const V3 p = random_in_unit_disk(rng);
-        origin = vadd(vadd(a.center, vscale(p.x, a.defocus_u)), vscale(p.y, a.defocus_v));
-    }
-    Ray r;
-    r.o = origin;
-    r.d = vsub(pixel_sample, origin);
-    r.tm = random_float(rng);
-    return r;
-}
-
-/* ---- light object sampling (pdf.cuh:60-80 over objects.cuh dispatchers) ---- */
-DEV float light_pdf_value(const DScene &sc, int type, int idx, V3 origin, V3 direction) {
-    if (type == MORT_OBJ_SPHERE) return wsphere_pdf_value(sc.wspheres[idx], origin, direction);
-    if (type == MORT_OBJ_QUAD) return wquad_pdf_value(sc.wquads[idx], origin, direction);
-    if (type == MORT_OBJ_HITTABLE_LIST) { /* objects.cuh:488-498 */
-        const int first = sc.list_first[idx], n = sc.list_count[idx];
-        const float weight = (float)(1.0 / (double)(float)n);
-        float sum = 0.0f;
-        for (int i = 0; i < n; i++) {
-            const int t = sc.list_types[first + i], k = sc.list_idxs[first + i];
-            float v = 0.0f;
-            if (t == MORT_OBJ_SPHERE) v = wsphere_pdf_value(sc.wspheres[k], origin, direction);
-            else if (t == MORT_OBJ_QUAD) v = wquad_pdf_value(sc.wquads[k], origin, direction);
-            sum += weight * v;
-        }
-        return sum;
-    }
-    return 0.0f; /* pdfValueDispatch default (objects.cuh:961) */
-}
-DEV V3 light_random(const DScene &sc, int type, int idx, V3 origin, Rng &rng) {
-    if (type == MORT_OBJ_HITTABLE_LIST) { /* objects.cuh:500-504 */
-        const int first = sc.list_first[idx], n = sc.list_count[idx];
-        const int k = random_int(rng, 0, n - 1);
-        type = sc.list_types[first + k];
-        idx = sc.list_idxs[first + k];
-        if (type == MORT_OBJ_HITTABLE_LIST) return mk(1, 0, 0); /* nested lists are rejected on the host */
-    }
-    if (type == MORT_OBJ_SPHERE) return wsphere_random(sc.wspheres[idx], origin, rng);
-    if (type == MORT_OBJ_QUAD) return wquad_random(sc.wquads[idx], origin, rng);
-    return mk(1, 0, 0); /* randomDispatch default (objects.cuh:978) */
-}
-
-/* one bounce-stack entry: k = scattering_pdf * attenuation, rp = 1 / pdf.
- * The unwind (camera.cuh:166-173) computes emission + (1/pdf)*((spdf*att)*final);
- * spdf*att and 1/pdf are the same fp32 values whenever they are formed, and the
- * pushed emission is always (0,0,0): only diffuse_light emits and it never scatters. */
-struct StackEntry { float kx, ky, kz, rp; };
 
 /* 3 waves per SIMD: without the bound the compiler takes 172 VGPRs, two over the limit for three */
 #ifndef MORT_GENERIC_WAVES
@@ -375,8 +293,12 @@ struct mort_ctx {
     unsigned *d_tile_cost = nullptr, *d_tile_order = nullptr;
     mort_rng_state *d_probe_states = nullptr;
     size_t tile_cap = 0, probe_cap = 0;
-    long long cost_key = -1; /* identifies the (geometry, partition, camera) the costs in d_tile_cost belong to */
-    std::vector<unsigned> h_cost, h_order;
+    unsigned long long cost_key = 0; /* hash of the (world, geometry, partition, camera basis) the costs in d_tile_cost belong to; 0 = none */
+    unsigned world_serial = 0;       /* bumped by upload_world: part of cost_key */
+    unsigned *d_tile_keys = nullptr, *d_tile_iota = nullptr; /* device argsort scratch (tile_sort.hip) */
+    void *d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    hipStream_t last_stream = nullptr; /* stream of the most recent render launch (may be the caller's) */
     /* wavefront mode work buffers */
     void *d_wf = nullptr;
     size_t wf_bytes = 0;
@@ -389,6 +311,16 @@ static int hip_fail(mort_ctx *c, hipError_t e, const char *what) {
     return MORT_ERR_HIP;
 }
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); } while (0)
+
+/* Wait for everything this context has launched: its own stream and, if a render went to a caller's stream, that one
+ * too -- before any call that reads, overwrites or frees what a render kernel uses (states, scene, counters). */
+static hipError_t quiesce(mort_ctx *c) {
+    hipError_t e = hipSuccess;
+    if (c->stream) e = hipStreamSynchronize(c->stream);
+    if (c->last_stream && c->last_stream != c->stream) { hipError_t e2 = hipStreamSynchronize(c->last_stream); if (e == hipSuccess) e = e2; }
+    c->last_stream = nullptr;
+    return e;
+}
 
 extern "C" const char *mort_hip_strerror(int st) {
     switch (st) {
@@ -478,7 +410,8 @@ extern "C" int mort_hip_init(int device, mort_ctx **out) {
 extern "C" void mort_hip_shutdown(mort_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
+    quiesce(c);
+    hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
     hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
     hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states);
@@ -493,7 +426,10 @@ extern "C" int mort_hip_set_partition(mort_ctx *c, const mort_partition *p) {
     if (!c || !p) return MORT_ERR_INVALID;
     if (p->nranks < 1 || p->rank < 0 || p->rank >= p->nranks || p->rows_per_block < 8 || (p->rows_per_block % 8) != 0)
         return MORT_ERR_INVALID;
+    hipSetDevice(c->device);
+    quiesce(c);
     c->part = *p;
+    c->cost_key = 0;
     /* RNG states are laid out per partition: force a re-seed */
     c->rng_w = c->rng_h = c->rng_local_rows = 0;
     return MORT_OK;
@@ -549,6 +485,8 @@ static size_t place(std::vector<unsigned char> &blob, const std::vector<T> &v) {
 extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     if (!c || !w) return MORT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, quiesce(c));
+    c->cost_key = 0; c->world_serial++;
     int st = validate_world(w);
     if (st != MORT_OK) return st;
     mortc::Compiler comp;
@@ -643,6 +581,7 @@ extern "C" int mort_hip_rng_seed(mort_ctx *c, uint64_t seed, int width, int heig
         HIPCHK(c, hipMalloc((void **)&c->d_seqmats, seq.size() * sizeof(XMat)));
         HIPCHK(c, hipMemcpy(c->d_seqmats, seq.data(), seq.size() * sizeof(XMat), hipMemcpyHostToDevice));
     }
+    HIPCHK(c, quiesce(c));
     int st = ensure_states(c, width, height);
     if (st != MORT_OK) return st;
     SeedArgs a;
@@ -668,6 +607,7 @@ extern "C" int mort_hip_rng_seed(mort_ctx *c, uint64_t seed, int width, int heig
 extern "C" int mort_hip_rng_load(mort_ctx *c, const mort_rng_state *states, int width, int height) {
     if (!c || !states || width <= 0 || height <= 0) return MORT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, quiesce(c));
     int st = ensure_states(c, width, height);
     if (st != MORT_OK) return st;
     for (int ly = 0; ly < c->rng_local_rows; ly++) {
@@ -681,7 +621,7 @@ extern "C" int mort_hip_rng_store(mort_ctx *c, mort_rng_state *states, int width
     if (!c || !states || width <= 0 || height <= 0) return MORT_ERR_INVALID;
     if (!c->d_states || c->rng_w != width || c->rng_h != height) return MORT_ERR_NO_RNG;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, quiesce(c));
     for (int ly = 0; ly < c->rng_local_rows; ly++) {
         const int y = global_row_host(c->part, ly);
         HIPCHK(c, hipMemcpy(states + (size_t)y * width, c->d_states + (size_t)ly * width, (size_t)width * sizeof(mort_rng_state), hipMemcpyDeviceToHost));
@@ -783,8 +723,11 @@ static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera 
     return MORT_OK;
 }
 
-extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum,
-                                      void *stream, mort_stats *stats) {
+/* d_segpx: per-pixel segment counts for the packed owned rows, or null.  Only mort_hip_render passes one (sized for
+ * THIS image and partition); the public device entry never does, so a buffer left over from an earlier, smaller
+ * render can not be written past its end. */
+static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum, uint32_t *d_segpx,
+                              void *stream, mort_stats *stats) {
     if (!c || !cam || !d_rgba) return MORT_ERR_INVALID;
     if (mode != MORT_MODE_MEGA && mode != MORT_MODE_WAVE) return MORT_ERR_INVALID;
     if (!c->have_world) return MORT_ERR_NO_WORLD;
@@ -796,6 +739,9 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     if (st != MORT_OK) return st;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    /* a render still running on another stream uses the same states and counters */
+    if (c->last_stream && c->last_stream != s) HIPCHK(c, hipStreamSynchronize(c->last_stream));
+    c->last_stream = s;
 
     RenderArgs a;
     std::memset(&a, 0, sizeof a);
@@ -811,7 +757,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
     a.rank = c->part.rank; a.nranks = c->part.nranks; a.rows_per_block = c->part.rows_per_block;
     a.local_rows = c->rng_local_rows;
     a.states = c->d_states;
-    a.rgba = (uchar4 *)d_rgba; a.accum = (float *)d_accum; a.seg_px = (uint32_t *)c->d_segpx;
+    a.rgba = (uchar4 *)d_rgba; a.accum = (float *)d_accum; a.seg_px = d_segpx;
     a.counters = c->d_counters;
 
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s));
@@ -824,6 +770,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
                           !(force && force[0] == '1');
     int lds_bytes_used = 0;
     const void *fast_kernel_used = nullptr;
+    char kname[64] = "mega_kernel";
     if (mode == MORT_MODE_WAVE) {
         /* the wavefront pipeline covers: one BVH of spheres as the world, no light object */
         if (!(c->wave_ok && c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1))
@@ -834,6 +781,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         int st_w = render_wavefront(c, a, cam, s);
         if (st_w != MORT_OK) return st_w;
         lds_bytes_used = (int)c->fast_bytes;
+        std::snprintf(kname, sizeof kname, "wf_trav<%d>", MORT_WF_BLOCK);
     } else if (blocks > 0 && use_fast) {
         FastArgs fa;
         std::memset(&fa, 0, sizeof fa);
@@ -893,19 +841,30 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         if (grid < 1) grid = 1;
         lds_bytes_used = (int)lds_bytes;
         fast_kernel_used = (const void *)kern;
+        std::snprintf(kname, sizeof kname, "mega_bvh_kernel<%d, false, %s>", FB, chain_bound ? "true" : "false");
         /* ---- tile order: expensive tiles first ---- */
         const bool want_order = !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid;
         if (want_order) {
             if (c->tile_cap < (size_t)tiles) {
-                if (c->d_tile_cost) { hipFree(c->d_tile_cost); hipFree(c->d_tile_order); c->d_tile_cost = c->d_tile_order = nullptr; c->tile_cap = 0; }
+                hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
+                c->d_tile_cost = c->d_tile_order = c->d_tile_keys = c->d_tile_iota = nullptr; c->d_sort_tmp = nullptr;
+                c->tile_cap = 0; c->sort_tmp_bytes = 0;
                 HIPCHK(c, hipMalloc((void **)&c->d_tile_cost, (size_t)tiles * sizeof(unsigned)));
                 HIPCHK(c, hipMalloc((void **)&c->d_tile_order, (size_t)tiles * sizeof(unsigned)));
+                HIPCHK(c, hipMalloc((void **)&c->d_tile_keys, (size_t)tiles * sizeof(unsigned)));
+                HIPCHK(c, hipMalloc((void **)&c->d_tile_iota, (size_t)tiles * sizeof(unsigned)));
+                c->sort_tmp_bytes = mort_tile_sort_temp_bytes(tiles);
+                HIPCHK(c, hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes ? c->sort_tmp_bytes : 16));
                 c->tile_cap = (size_t)tiles;
-                c->cost_key = -1;
+                c->cost_key = 0;
             }
-            long long key = (long long)W * 1000003LL + (long long)a.local_rows * 10007LL + (long long)a.rank * 101LL + a.nranks;
-            key = key * 31 + cam->bounce_limit;
-            key = key * 31 + (long long)(cam->lookfrom.e[0] * 1024.0f) + (long long)(cam->lookfrom.e[2] * 7.0f) + (long long)(cam->lookat.e[0] * 3.0f) + cam->vfov;
+            /* the costs belong to one (world, image geometry, partition, view): FNV-1a over all of it */
+            unsigned long long key = 1469598103934665603ull;
+            auto mix = [&key](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ull; } };
+            { const int g[8] = {W, H, a.local_rows, a.rank, a.nranks, a.rows_per_block, cam->bounce_limit, (int)c->world_serial}; mix(g, sizeof g); }
+            mix(&a.center, sizeof a.center); mix(&a.pixel00, sizeof a.pixel00); mix(&a.du, sizeof a.du); mix(&a.dv, sizeof a.dv);
+            mix(&a.defocus_angle, sizeof a.defocus_angle);
+            if (key == 0) key = 1;
             if (c->cost_key != key) { /* no history for this view: one-sample probe on a scratch copy of the streams */
                 const size_t npx = (size_t)W * (size_t)a.local_rows;
                 if (c->probe_cap < npx) {
@@ -925,14 +884,8 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
                 HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
                 c->cost_key = key;
             }
-            /* order = argsort(cost, descending); 12.6 k tiles for the headline frame: done on the host */
-            c->h_cost.resize((size_t)tiles); c->h_order.resize((size_t)tiles);
-            HIPCHK(c, hipMemcpyAsync(c->h_cost.data(), c->d_tile_cost, (size_t)tiles * sizeof(unsigned), hipMemcpyDeviceToHost, s));
-            HIPCHK(c, hipStreamSynchronize(s));
-            for (int i = 0; i < tiles; i++) c->h_order[i] = (unsigned)i;
-            const unsigned *cost = c->h_cost.data();
-            std::stable_sort(c->h_order.begin(), c->h_order.end(), [cost](unsigned x, unsigned y) { return cost[x] > cost[y]; });
-            HIPCHK(c, hipMemcpyAsync(c->d_tile_order, c->h_order.data(), (size_t)tiles * sizeof(unsigned), hipMemcpyHostToDevice, s));
+            /* order = argsort(cost, descending, equal costs by index), on the device and on this stream */
+            HIPCHK(c, mort_tile_sort_desc(c->d_tile_cost, c->d_tile_keys, c->d_tile_iota, c->d_tile_order, c->d_sort_tmp, c->sort_tmp_bytes, tiles, s));
             HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
             fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost;
             fa.gen_tiles = grid * (FB / 64); /* one tile's worth of slots per wave in flight */
@@ -998,6 +951,7 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         stats->scene_in_lds = (use_fast || mode == MORT_MODE_WAVE) ? 1 : 0;
         if (mode == MORT_MODE_WAVE) stats->algorithmic_hbm_bytes += 240ull * stats->segments; /* wave_bvh.h: per-segment record traffic */
         stats->local_rows = a.local_rows;
+        std::memcpy(stats->kernel_name, kname, sizeof stats->kernel_name);
         hipFuncAttributes fattr;
         const void *kf = mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
                          : fast_kernel_used;
@@ -1007,6 +961,11 @@ extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int m
         }
     }
     return MORT_OK;
+}
+
+extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum,
+                                      void *stream, mort_stats *stats) {
+    return render_device_impl(c, cam, mode, d_rgba, d_accum, nullptr, stream, stats);
 }
 
 static int ensure_buf(mort_ctx *c, void **p, size_t *cap, size_t need) {
@@ -1031,7 +990,8 @@ extern "C" int mort_hip_render(mort_ctx *c, const mort_camera *cam, int mode, ui
     if (segments_px_out) { if ((st = ensure_buf(c, &c->d_segpx, &c->segpx_cap, npx * 4)) != MORT_OK) return st; }
     else if (c->d_segpx) { hipFree(c->d_segpx); c->d_segpx = nullptr; c->segpx_cap = 0; }
     mort_stats local;
-    st = mort_hip_render_device(c, cam, mode, c->d_rgba, accum_out ? c->d_accum : nullptr, nullptr, &local);
+    st = render_device_impl(c, cam, mode, c->d_rgba, accum_out ? c->d_accum : nullptr,
+                            segments_px_out ? (uint32_t *)c->d_segpx : nullptr, nullptr, &local);
     if (st != MORT_OK) return st;
     if (stats) *stats = local;
     if (c->part.nranks == 1) { /* packed rows are the whole image: three copies instead of one per row */

@@ -35,10 +35,12 @@ class Stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("segments", C.c_uint64), ("pixels", C.c_uint64),
                 ("eff_samples", C.c_uint64), ("rng_draws", C.c_uint64), ("algorithmic_hbm_bytes", C.c_uint64),
                 ("scene_in_lds", C.c_int), ("local_rows", C.c_int), ("kernel_vgprs", C.c_int),
-                ("kernel_lds_bytes", C.c_int), ("reference_walks", C.c_uint64)]
+                ("kernel_lds_bytes", C.c_int), ("reference_walks", C.c_uint64), ("kernel_name", C.c_char * 64)]
 
     def asdict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["kernel_name"] = d["kernel_name"].decode()
+        return d
 
 
 class MortHipError(RuntimeError):

@@ -395,3 +395,53 @@ def test_empty_world_renders_background(gpu_ctx, oracle):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_render_device_after_smaller_render_with_segments(gpu_ctx, oracle):
+    """a per-pixel segment buffer left by an earlier, smaller mort_hip_render must not be written by a
+    later mort_hip_render_device on a bigger frame (it is an internal argument now, never taken from the context)."""
+    import torch
+    world, cam_s = host.build_scene(1, width=64, spp=1)
+    gpu_ctx.set_partition(0, 1, 8)
+    gpu_ctx.upload_world(world)
+    gpu_ctx.rng_seed(S.DEFAULT_SEED, cam_s.image_width, cam_s.image_height)
+    gpu_ctx.render(cam_s, want_segments=True)
+    world_b, cam_b = host.build_scene(1, width=400, spp=4)
+    gpu_ctx.upload_world(world_b)
+    W, H = cam_b.image_width, cam_b.image_height
+    gpu_ctx.rng_seed(S.DEFAULT_SEED, W, H)
+    tile = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+    guard = torch.zeros(1 << 20, dtype=torch.uint8, device="cuda:0")  # neighbours in the caching allocator stay zero
+    torch.cuda.synchronize()
+    st = gpu_ctx.render_device(cam_b, tile.data_ptr(), 0, 0, sync=True)
+    ref = oracle.render(world_b, cam_b, nthreads=8)
+    assert (tile.cpu().numpy() == ref["rgba"]).all() and st["segments"] == ref["segments"]
+    assert int(guard.sum().item()) == 0
+
+
+def test_async_render_device_then_store(gpu_ctx, oracle):
+    """render_device(stats=NULL) on a caller stream returns without waiting (the tile order is sorted on the device);
+    rng_store afterwards waits for that stream (stream ownership) and sees the finished states."""
+    import torch
+    world, cam = host.build_scene(1, width=320, spp=9)
+    W, H = cam.image_width, cam.image_height
+    gpu_ctx.set_partition(0, 1, 8)
+    gpu_ctx.upload_world(world)
+    gpu_ctx.rng_seed(S.DEFAULT_SEED, W, H)
+    stream = torch.cuda.Stream("cuda:0")
+    tile = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu_ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, sync=False)
+    got = gpu_ctx.rng_store(W, H, oracle.STATE_DTYPE)  # must wait for the caller's stream
+    ref = oracle.render(world, cam, nthreads=8)
+    assert (got["d"] == ref["states"]["d"]).all() and (got["v"] == ref["states"]["v"]).all()
+    stream.synchronize()
+    assert (tile.cpu().numpy() == ref["rgba"]).all()
+    # second frame of the same view takes the cost-ordered path with history; a moved camera invalidates it
+    gpu_ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, sync=False)
+    world2, cam2 = host.build_scene(10, width=320, spp=4)
+    gpu_ctx.upload_world(world2)  # waits for the frame in flight, drops the cost history
+    gpu_ctx.rng_seed(S.DEFAULT_SEED, cam2.image_width, cam2.image_height)
+    tile2 = torch.zeros((cam2.image_height, cam2.image_width, 4), dtype=torch.uint8, device="cuda:0")
+    gpu_ctx.render_device(cam2, tile2.data_ptr(), 0, stream.cuda_stream, sync=True)
+    assert (tile2.cpu().numpy() == oracle.render(world2, cam2, nthreads=8)["rgba"]).all()
