@@ -19,7 +19,7 @@ INC := -Iinclude
 
 CFLAGS := -O2 -std=gnu11 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -fno-fast-math $(INC)
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
-            -fno-gpu-rdc -Wall -Wno-unused-parameter -Wno-unused-value -Wno-unused-result $(INC)
+            -fno-gpu-rdc -Wall -Wno-unused-parameter -Wno-unused-value -Wno-unused-result $(INC) $(HIPFLAGS_EXTRA)
 
 HOST_SRC := mort_amd/csrc/host/mort_host.c mort_amd/csrc/host/mort_scenes.c
 HIP_SRC := $(wildcard mort_amd/csrc/hip/*.hip)

@@ -111,6 +111,16 @@ int mort_hip_render(mort_ctx *ctx, const mort_camera *cam, int mode, uint8_t *rg
 int mort_hip_render_device(mort_ctx *ctx, const mort_camera *cam, int mode, void *d_rgba, void *d_accum,
                            void *stream, mort_stats *stats);
 
+/* ---- `mort --mode host` (BASELINE config 1; the CPU figure timed beside the GPU): the render path as a straight host
+ * loop of the SAME kernel body the GPU runs (camera.cuh:86-242 and everything below it), on `nthreads` host threads.
+ * An explicit mode, never a fallback; needs no GPU and makes no HIP runtime call.  `states`: W*H records, read and
+ * written in place (full image, row 0 = bottom row).  flags: MORT_HOST_TREE = walk this build's unified tree where the
+ * world has one (what one GPU lane does) instead of the reference's scan over every primitive. ---- */
+#define MORT_HOST_TREE 1
+int mort_hip_rng_seed_host(uint64_t seed, int width, int height, mort_rng_state *states);
+int mort_hip_render_host(const mort_world *world, const mort_camera *cam, mort_rng_state *states, int nthreads, int flags,
+                         uint8_t *rgba_out, float *accum_out, uint32_t *segments_px_out, mort_stats *stats);
+
 /* Number of rows owned for an image of `height` rows under the current partition. */
 int mort_hip_local_rows(const mort_ctx *ctx, int height);
 /* Global row index of local row `local_row`. */

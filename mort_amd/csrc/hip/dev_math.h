@@ -14,7 +14,7 @@
 
 #pragma clang fp contract(off)
 
-#define DEV __device__ __forceinline__
+#define DEV __host__ __device__ __forceinline__ /* the host loop (host_render.hip) runs the same bodies */
 
 struct V3 { float x, y, z; };
 DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }

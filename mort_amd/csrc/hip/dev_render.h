@@ -28,6 +28,7 @@ struct RenderArgs {
     float *accum;          /* may be null */
     uint32_t *seg_px;      /* may be null */
     unsigned long long *counters; /* [0] segments, [1] rng draws */
+    int debug_lofs;        /* -DMORT_DEBUG_PRINT builds: packed pixel offset whose segments are printed (MORT_DEBUG_PIXEL), else unused */
 };
 
 DEV int global_row(int ly, int rank, int nranks, int rpb) {

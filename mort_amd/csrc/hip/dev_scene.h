@@ -61,6 +61,12 @@ struct __attribute__((aligned(16))) DNode2 {
 };
 #define MORT_OWN_STACK 16 /* pending far children per lane kept in LDS; deeper walks use the reference walk */
 #define MORT_OWN_MAX_DEPTH 15
+/* unified tree (scene_compile.h build_unified): at most this many primitives per leaf; an entry names one primitive */
+#define MORT_GEN_LEAF_MAX 4
+#define GENT(kind, chain, idx) (((uint32_t)(kind) << 31) | ((uint32_t)(chain) << 24) | (uint32_t)(idx))
+#define GENT_QUAD(e) ((e) >> 31)
+#define GENT_CHAIN(e) (((e) >> 24) & 0x7fu)
+#define GENT_IDX(e) ((e) & 0xffffffu)
 
 enum { XF_TRANSLATE = 0, XF_ROTATE_Y = 1 };
 struct __attribute__((aligned(16))) DXform { /* 16 B */
@@ -102,6 +108,7 @@ struct DScene {
     const DLambert *lambert; const DMetal *metal; const DDielectric *dielectric;
     const DLambert *dlight;  const DLambert *isotropic; /* {rgb | tex} like lambertian */
     const DSolid *solid; const DChecker *checker; const DImage *image;
+    const DImage *image_hbm; /* == image; stays the HBM copy in a kernel's LDS view of the scene (image_value is out of line) */
     const unsigned char *texels;
     const float *noise;     /* mort_noise_texture records, 6152 B each */
     /* light sampling reads objects by their WORLD index (camera.light_obj_*):

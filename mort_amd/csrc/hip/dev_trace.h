@@ -427,8 +427,10 @@ DEV float perlin_noise(const float *nt, V3 p) { /* textures.cuh:174-196,232-250 
             }
     return (float)accum;
 }
-__device__ __attribute__((noinline)) V3 noise_value(const DScene &sc, int idx, V3 p) { /* out of line: 7 x 8 gradient fetches, fp64 accumulators */ /* textures.cuh:198-202,252-265 */
-    const float *nt = sc.noise + (size_t)idx * (sizeof(mort_noise_texture) / 4);
+/* out of line: 7 x 8 gradient fetches, fp64 accumulators (textures.cuh:198-202,252-265).  Takes the table pointer, not
+ * the scene: a kernel's scene view with LDS-resident tables then never escapes to a call */
+static __host__ __device__ __attribute__((noinline)) V3 noise_value(const float *noise, int idx, V3 p) {
+    const float *nt = noise + (size_t)idx * (sizeof(mort_noise_texture) / 4);
     const float scale = nt[3 * MORT_POINT_COUNT + 3 * MORT_POINT_COUNT];
     const V3 s = vscale(scale, p);
     double accum = 0.0;
@@ -443,8 +445,8 @@ __device__ __attribute__((noinline)) V3 noise_value(const DScene &sc, int idx, V
     const V3 half = vscale(0.5f, mk(1, 1, 1));
     return vscale((float)(1 + mort_sin((double)s.z + 10.0 * (double)turb)), half);
 }
-__device__ __attribute__((noinline)) V3 image_value(const DScene &sc, int idx, float u, float v) { /* textures.cuh:129-146 */
-    const DImage im = sc.image[idx];
+static __host__ __device__ __attribute__((noinline)) V3 image_value(const DImage *image, const unsigned char *texels, int idx, float u, float v) { /* textures.cuh:129-146 */
+    const DImage im = image[idx];
     if (im.height <= 0) return mk(0, 1, 1);
     u = clamp01(u);
     v = (float)(1.0 - (double)clamp01(v));
@@ -459,7 +461,7 @@ __device__ __attribute__((noinline)) V3 image_value(const DScene &sc, int idx, f
         int x = i * 3 + k;
         if (x < 0) x = 0;
         if (x > row_bytes - 1) x = row_bytes - 1;
-        rgb[k] = sc.texels[(size_t)im.offset + (size_t)j * row_bytes + x];
+        rgb[k] = texels[(size_t)im.offset + (size_t)j * row_bytes + x];
     }
     const float color_scale = (float)(1.0 / 255.0);
     return mk(color_scale * (float)rgb[0], color_scale * (float)rgb[1], color_scale * (float)rgb[2]);
@@ -477,8 +479,8 @@ DEV V3 texture_value(const DScene &sc, uint32_t tex, float u, float v, V3 p) { /
             tex = ((xi + yi + zi) % 2 == 0) ? c.even : c.odd;
             continue;
         }
-        if (type == MORT_TEXTURE_IMAGE) return image_value(sc, idx, u, v);
-        if (type == MORT_TEXTURE_NOISE) return noise_value(sc, idx, p);
+        if (type == MORT_TEXTURE_IMAGE) return image_value(sc.image_hbm, sc.texels, idx, u, v);
+        if (type == MORT_TEXTURE_NOISE) return noise_value(sc.noise, idx, p);
         break;
     }
     const float error = (float)((mort_f2i(mort_floorf((float)((double)u * 1000.0))) % 2) ==

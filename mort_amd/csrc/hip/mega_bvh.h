@@ -44,7 +44,7 @@
 #ifndef MORT_MEGA_BVH_H
 #define MORT_MEGA_BVH_H
 
-#include "dev_trace.h"
+#include "dev_render.h"
 
 struct FastArgs {
     RenderArgs r;

@@ -1,0 +1,377 @@
+/*
+ * mega_gen.hip -- state-machine megakernel for worlds without reference BVHs: reference scenes 2..9 (two spheres,
+ * earth, Perlin, quads, Cornell box, Cornell smoke, the book-2 final scene), i.e. everything the reference traces
+ * with the brute-force loops of world::hit (world.cuh:122-168) over spheres, quads, translate / rotate_y instances,
+ * hittable lists and constant media (objects.cuh:60-77,190-215,268-278,334-366,396-434,471-486), shaded with all five
+ * materials, four textures and the light / material mixture pdf (materials.cuh, textures.cuh, pdf.cuh).
+ *
+ * CDNA4 design (the generalisation of mega_bvh.h to arbitrary object graphs):
+ *
+ *  - Unified tree in LDS.  All solid primitives of the world -- whatever instance chain or list they sit under --
+ *    are leaves of ONE tree of this build (scene_compile.h build_unified: SAH, 64-byte two-child nodes, leaves of at
+ *    most MORT_GEN_LEAF_MAX primitives).  Nodes, leaf table, primitive entries, transform chains, item / material /
+ *    texture tables are copied to LDS once per workgroup; spheres and quads too when they fit (scenes 2..7), else
+ *    they stay L2-resident (final scene: 2401 quads x 80 B).  A box step reads one node with four ds_read_b128.
+ *    The reference scans every primitive per ray (3 408 tests per segment in the final scene).
+ *
+ *  - Why the tree gives the scan's answer: header of build_unified.  The scan's result is the primitive with the
+ *    smallest own t, ties -> scanned last; the walk sees every primitive whose own t is <= the final closest, keeps
+ *    the minimum and FLAGS equal t; flagged rays, and rays whose reciprocal direction is not an ordinary float,
+ *    repeat the segment with the scan itself (scan_solids, out of line, about never).  Constant media are evaluated
+ *    after the tree with the final closest_so_far, in scan order, as world::hit does (their RNG draw depends on it).
+ *
+ *  - Per-lane state machine, wave-level scheduling (as mega_bvh.h): T both child boxes of a node, L the primitives
+ *    of a leaf, M the constant media, S shade / finish / next sample / next pixel.  Each wave iteration runs one
+ *    state's code for the lanes in it, picked from ballot / popcount thresholds; a lane whose path ends never waits
+ *    for the wave's longest path, and lanes fetch pixels from one atomic counter (cost-ordered 8x8 tiles).
+ *
+ *  - XORWOW state in 6 VGPRs for the pixel's lifetime; bounce stack (scattering_pdf * attenuation, 1 / pdf) with its
+ *    first levels in LDS ([depth][thread], conflict-free b128), identity (dielectric) levels not stored at all.
+ *
+ * Shading is dev_shade.h's shade_hit(), the same body the one-lane-per-pixel kernel and the host loop run.
+ */
+#include <hip/hip_runtime.h>
+
+#include "mega_gen.h"
+#include "dev_gen.h"
+#include "dev_shade.h"
+
+#pragma clang fp contract(off)
+
+enum { G_T = 0, G_L = 1, G_M = 2, G_S = 3, G_DONE = 4 };
+
+#ifndef MORT_GEN_MIN_WAVES
+#define MORT_GEN_MIN_WAVES 3
+#endif
+
+/* the scan for the rays the walk does not decide (equal t, non-ordinary reciprocals): out of line, reads the HBM copy */
+struct ScanHit { uint32_t best; float closest; };
+__device__ __attribute__((noinline)) ScanHit scan_solids(const DScene *scp, int first_medium, const int *chains, int n_chains,
+                                                         float ox, float oy, float oz, float dx, float dy, float dz, float tm) {
+    Ray r; r.o = mk(ox, oy, oz); r.d = mk(dx, dy, dz); r.tm = tm;
+    ScanHit h;
+    gen_scan_solids(*scp, first_medium, chains, n_chains, r, h.closest, h.best);
+    return h;
+}
+
+/* Shading is out of line: one call per segment with everything passed in registers.  (Inlined into the state loop, hipcc 7.2
+ * -O3 produced a kernel whose scattered-ray origin was wrong for a few rays per thousand -- correct at -O1, correct with
+ * a printf next to it, correct out of line; the parity tests against the oracle are what guards this.)  It also keeps the
+ * shade step's registers out of the traversal steps. */
+struct ShadeRet { float ox, oy, oz, dx, dy, dz, tm, kx, ky, kz, rp, fx, fy, fz; int flags; uint32_t d, v0, v1, v2, v3, v4, draws; };
+__device__ __attribute__((noinline)) ShadeRet shade_call(const DScene *scp, int light_type, int light_idx, float ox, float oy, float oz, float dx, float dy, float dz, float tm,
+                                                         float time0, float t, int kind, int prim, int cf, int cc, uint32_t d, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t draws) {
+    Ray ray; ray.o = mk(ox, oy, oz); ray.d = mk(dx, dy, dz); ray.tm = tm;
+    Best b; b.t = t; b.kind = kind; b.prim = prim; b.chain_first = cf; b.chain_count = cc;
+    Rng rng; rng.d = d; rng.v0 = v0; rng.v1 = v1; rng.v2 = v2; rng.v3 = v3; rng.v4 = v4; rng.draws = draws;
+    const ShadeOut so = shade_hit(*scp, light_type, light_idx, ray, time0, b, rng);
+    ShadeRet r;
+    r.ox = ray.o.x; r.oy = ray.o.y; r.oz = ray.o.z; r.dx = ray.d.x; r.dy = ray.d.y; r.dz = ray.d.z; r.tm = ray.tm;
+    r.kx = so.e.kx; r.ky = so.e.ky; r.kz = so.e.kz; r.rp = so.e.rp; r.fx = so.final_value.x; r.fy = so.final_value.y; r.fz = so.final_value.z;
+    r.flags = (so.done ? 1 : 0) | (so.ident ? 2 : 0);
+    r.d = rng.d; r.v0 = rng.v0; r.v1 = rng.v1; r.v2 = rng.v2; r.v3 = rng.v3; r.v4 = rng.v4; r.draws = rng.draws;
+    return r;
+}
+
+template <int BLOCK, bool PRIMS_LDS>
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)) mega_gen_kernel(const GenArgs ga) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ DScene s_lsc; /* the scene view below, for the out-of-line shade call */
+    const FastArgs &fa = ga.f;
+    const RenderArgs &a = fa.r;
+    {
+        const uint4 *src = (const uint4 *)fa.hot_src;
+        uint4 *dst = (uint4 *)lds;
+        const uint32_t n16 = fa.hot_bytes >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const DNode2 *nodes2 = (const DNode2 *)(lds + ga.o_nodes);
+    const uint32_t *leaves = (const uint32_t *)(lds + ga.o_leaves);
+    const uint32_t *entries = (const uint32_t *)(lds + ga.o_entries);
+    const int *chains = (const int *)(lds + ga.o_chains);
+    unsigned short *tstack = (unsigned short *)(lds + fa.off_tstack) + threadIdx.x; /* [level * BLOCK] */
+    /* this kernel's view of the scene: tables in LDS, big / rare ones (texels, Perlin tables, image descriptors for the
+     * out-of-line lookups; primitives of big worlds) in HBM */
+    DScene lsc = a.sc;
+    lsc.items = (const DItem *)(lds + ga.o_items); lsc.subitems = (const DItem *)(lds + ga.o_subitems);
+    lsc.xforms = (const DXform *)(lds + ga.o_xforms); lsc.neg_inv_density = (const double *)(lds + ga.o_media);
+    lsc.lambert = (const DLambert *)(lds + ga.o_lambert); lsc.metal = (const DMetal *)(lds + ga.o_metal);
+    lsc.dielectric = (const DDielectric *)(lds + ga.o_diel); lsc.dlight = (const DLambert *)(lds + ga.o_dlight);
+    lsc.isotropic = (const DLambert *)(lds + ga.o_iso); lsc.solid = (const DSolid *)(lds + ga.o_solid);
+    lsc.checker = (const DChecker *)(lds + ga.o_checker); lsc.image = (const DImage *)(lds + ga.o_image);
+    if (PRIMS_LDS) {
+        lsc.spheres = (const DSphere *)(lds + ga.o_spheres); lsc.quads = (const DQuad *)(lds + ga.o_quads);
+        lsc.wspheres = (const DSphere *)(lds + ga.o_wspheres); lsc.wquads = (const DQuad *)(lds + ga.o_wquads);
+        lsc.list_types = (const int *)(lds + ga.o_ltypes); lsc.list_idxs = (const int *)(lds + ga.o_lidxs);
+    }
+    if (ga.lane_walk & 2) lsc = a.sc; /* test knob: every table from HBM */
+    if (threadIdx.x == 0) s_lsc = lsc;
+    __syncthreads();
+    const DSphere *spheres = lsc.spheres;
+    const DQuad *quads = lsc.quads;
+
+    const int th_s = fa.th_s, th_l = fa.th_l, t_keep = fa.t_keep, th_m = ga.th_m;
+    const int spp = a.sqrt_spp * a.sqrt_spp;
+    const unsigned total_q = (unsigned)fa.tiles_total * 64u;
+    const int n_items = a.sc.n_items, first_medium = ga.first_medium;
+    const bool has_media = first_medium < n_items;
+
+    /* per-lane state */
+    int state = G_S, kind = K_NEWPIX;
+    int xy = 0, lofs = 0;
+    Rng rng; rng.d = rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = 0; rng.draws = 0;
+    V3 pixel_color = mk(0, 0, 0);
+    int s_ij = 0, iter = 0;
+    uint32_t segments = 0;
+    Ray ray; ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); ray.tm = 0;
+    float ray_time0 = 0;
+    GenRay gr; gr.ix = gr.iy = gr.iz = 1; gr.mx = gr.my = gr.mz = 0; gr.band = 0;
+    float ray_a = 1, closest = 0;
+    uint32_t best = GBEST_NONE; /* entry code of the closest hit so far */
+    uint32_t node = 0;          /* T: tree node; L: leaf */
+    int sp = 0, flags = 0;      /* pending far children; FL_TIE / FL_REF */
+    V3 final_value = mk(0, 0, 0);
+    StackEntry stack_deep[MORT_MAX_BOUNCE_LIMIT];
+    unsigned long long ident_mask = 0ull;
+    float4 *stack_lds = (float4 *)(lds + fa.off_stack);
+    const int DL = fa.stack_lds_depth;
+
+    for (;;) {
+        const unsigned long long mT = __ballot(state == G_T);
+        const unsigned long long mL = __ballot(state == G_L);
+        const unsigned long long mM = __ballot(state == G_M);
+        const unsigned long long mS = __ballot(state == G_S);
+        if ((mT | mL | mM | mS) == 0ull) break;
+        const int nT = __popcll(mT), nL = __popcll(mL), nM = __popcll(mM), nS = __popcll(mS);
+        int pick;
+        if (nS >= th_s) pick = G_S;
+        else if (nM >= th_m) pick = G_M;
+        else if (nL >= th_l) pick = G_L;
+        else if (nT > 0) pick = G_T;
+        else pick = (nL >= nS && nL >= nM) ? G_L : (nM >= nS ? G_M : G_S);
+
+        if (pick == G_T) {
+            /* ---- box steps: both child boxes of one node, near child next, far child pushed ---- */
+            int keep;
+            do {
+#pragma unroll
+                for (int rep = 0; rep < MORT_T_UNROLL; rep++) {
+                    if (state == G_T) {
+                        const float4 *np = (const float4 *)(nodes2 + node);
+                        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                        float te0, te1;
+                        const bool m0 = gen_prune(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, gr, closest, te0);
+                        const bool m1 = gen_prune(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, gr, closest, te1);
+                        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                        const bool both = !m0 && !m1, none = m0 && m1;
+                        const bool first0 = te0 <= te1;
+                        uint32_t next = both ? (first0 ? c0 : c1) : (m0 ? c1 : c0);
+                        if (both) tstack[sp * BLOCK] = (unsigned short)(first0 ? c1 : c0);
+                        sp += both ? 1 : 0;
+                        const bool have = !none || sp > 0;
+                        if (none && sp > 0) { sp--; next = tstack[sp * BLOCK]; }
+                        if (!have) { state = has_media ? G_M : G_S; kind = K_SHADE; }
+                        else { node = next & 0x7fffu; if (next & 0x8000u) state = G_L; }
+                    }
+                }
+                keep = __popcll(__ballot(state == G_T));
+            } while (keep >= t_keep);
+        } else if (pick == G_L) {
+            /* ---- leaf: the own hit test of each primitive of the leaf, in its own frame
+             *      (sphere::hit objects.cuh:60-77, quad::hit :190-215 under translate / rotate_y :268-278,334-366) ---- */
+            uint32_t pos = 0;
+            int cnt = 0;
+            if (state == G_L) { const uint32_t rec = leaves[node]; pos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
+            while (__ballot(cnt > 0) != 0ull) {
+                if (cnt > 0) {
+                    gen_leaf_test(lsc, chains, spheres, quads, entries[pos], ray, ray_a, closest, best, flags);
+                    pos++; cnt--;
+                }
+            }
+            if (state == G_L) {
+                if (sp > 0) {
+                    sp--;
+                    const uint32_t next = tstack[sp * BLOCK];
+                    node = next & 0x7fffu;
+                    state = (next & 0x8000u) ? G_L : G_T;
+                } else { state = (has_media || flags) ? G_M : G_S; kind = K_SHADE; }
+            }
+        } else if (pick == G_M) {
+            /* ---- after the solids: the scan itself for undecided rays, then the constant media in scan order
+             *      (constant_medium::hit, objects.cuh:396-434; world.cuh:154-160) ---- */
+            if (state == G_M) {
+                if (flags) {
+                    atomicAdd(&a.counters[3], 1ull);
+                    const ScanHit h = scan_solids(&a.sc, first_medium, (const int *)(fa.hot_src + ga.o_chains), ga.n_chains, ray.o.x, ray.o.y, ray.o.z,
+                                                  ray.d.x, ray.d.y, ray.d.z, ray.tm);
+                    best = h.best; closest = h.closest;
+                    flags = 0;
+                }
+                gen_media(lsc, first_medium, n_items, ray, rng, closest, best);
+                state = G_S; kind = K_SHADE;
+            }
+        } else {
+            /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
+            if (state == G_S) {
+                if (kind == K_SHADE) {
+                    if (flags) { /* worlds without media come here directly */
+                        atomicAdd(&a.counters[3], 1ull);
+                        const ScanHit h = scan_solids(&a.sc, first_medium, (const int *)(fa.hot_src + ga.o_chains), ga.n_chains, ray.o.x, ray.o.y, ray.o.z,
+                                                      ray.d.x, ray.d.y, ray.d.z, ray.tm);
+                        best = h.best; closest = h.closest;
+                        flags = 0;
+                    }
+#ifdef MORT_DEBUG_PRINT
+                    if (lofs == a.debug_lofs) printf("[gen %d seg %u] o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) tm %.9g -> best %08x t %.9g draws %u\n", lofs, segments,
+                        ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tm, best, closest, rng.draws);
+#endif
+                    if (best == GBEST_NONE) { /* camera.cuh:154-158 */
+                        final_value = a.background;
+                        kind = K_FINISH;
+                    } else {
+                        const Best b = gen_decode_best(lsc, chains, best, closest);
+#ifdef MORT_DEBUG_PRINT
+                        if (lofs == a.debug_lofs) printf("   decode: kind %d prim %d chain %d+%d t %.9g | chains[0..3] %d %d %d %d o_chains %u\n", b.kind, b.prim, b.chain_first, b.chain_count, b.t,
+                            chains[0], chains[1], chains[2], chains[3], ga.o_chains);
+#endif
+                        ShadeOut so;
+                        {
+                            const ShadeRet r = shade_call(&s_lsc, a.light_type, a.light_idx, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tm, ray_time0,
+                                                          b.t, b.kind, b.prim, b.chain_first, b.chain_count, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4, rng.draws);
+                            ray.o = mk(r.ox, r.oy, r.oz); ray.d = mk(r.dx, r.dy, r.dz); ray.tm = r.tm;
+                            so.e.kx = r.kx; so.e.ky = r.ky; so.e.kz = r.kz; so.e.rp = r.rp; so.final_value = mk(r.fx, r.fy, r.fz);
+                            so.done = r.flags & 1; so.ident = (r.flags & 2) != 0;
+                            rng.d = r.d; rng.v0 = r.v0; rng.v1 = r.v1; rng.v2 = r.v2; rng.v3 = r.v3; rng.v4 = r.v4; rng.draws = r.draws;
+                        }
+#ifdef MORT_DEBUG_PRINT
+                        if (lofs == a.debug_lofs) printf("   shaded: done %d ident %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", (int)so.done, (int)so.ident, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+#endif
+                        if (so.done) { final_value = so.final_value; kind = K_FINISH; }
+                        else {
+                            if (so.ident) ident_mask |= (1ull << iter);
+                            else if (iter < DL) { float4 e4; e4.x = so.e.kx; e4.y = so.e.ky; e4.z = so.e.kz; e4.w = so.e.rp; stack_lds[iter * BLOCK + threadIdx.x] = e4; }
+                            else stack_deep[iter] = so.e;
+                            iter++;
+                            if (iter >= a.bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
+                        }
+                    }
+                }
+                if (kind == K_FINISH) { /* unwind + accumulate (camera.cuh:165-173,190); see mega_bvh.h for the identity levels */
+                    if (iter > 0) {
+                        unsigned long long todo = ~ident_mask & (iter >= 64 ? ~0ull : ((1ull << iter) - 1ull));
+                        if ((ident_mask >> (iter - 1)) & 1ull) final_value = vadd(mk(0, 0, 0), final_value);
+                        while (todo != 0ull) {
+                            const int lvl = 63 - __builtin_clzll(todo);
+                            todo &= ~(1ull << lvl);
+                            StackEntry e;
+                            if (lvl < DL) { const float4 e4 = stack_lds[lvl * BLOCK + threadIdx.x]; e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w; }
+                            else e = stack_deep[lvl];
+                            const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
+                            final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
+                        }
+                        iter = 0;
+                    }
+                    ident_mask = 0ull;
+                    pixel_color = vadd(pixel_color, final_value);
+                    s_ij++;
+                    if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
+                    if ((s_ij >> 16) < a.sqrt_spp) {
+                        kind = K_NEWSAMPLE;
+                    } else {
+                        if (ga.probe) pixel_write<true>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        else pixel_write<false>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        kind = K_NEWPIX;
+                    }
+                }
+                if (kind == K_NEWPIX) {
+                    const PixelFetch pf = pixel_fetch(&fa, total_q);
+                    if (!pf.got) state = G_DONE;
+                    else {
+                        xy = pf.xy; lofs = pf.lofs;
+                        rng.d = pf.d; rng.v0 = pf.v0; rng.v1 = pf.v1; rng.v2 = pf.v2; rng.v3 = pf.v3; rng.v4 = pf.v4;
+                        rng.draws = 0;
+                        pixel_color = mk(0, 0, 0);
+                        s_ij = 0; segments = 0;
+                        kind = (spp > 0) ? K_NEWSAMPLE : K_FINISH;
+                        if (spp <= 0) final_value = mk(0, 0, 0);
+                    }
+                }
+                if (state != G_DONE) {
+                    if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
+                        ray = get_ray(a, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
+                        ray_time0 = ray.tm;
+                        iter = 0;
+                        kind = K_SHADE;
+                        if (a.bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
+                    }
+                    if (kind == K_SHADE) { /* start world::hit for the new ray */
+                        ray_a = vlen2(ray.d);
+                        const bool ordinary = gen_ray_setup(ray, ga.gx, ga.gy, ga.gz, ga.gR, ga.mnear, ga.kmin, gr);
+                        closest = __builtin_inff();
+                        best = GBEST_NONE;
+                        sp = 0;
+                        flags = ordinary ? 0 : GFL_REF;
+                        segments++;
+                        const uint32_t root = ga.root;
+                        if (ga.lane_walk & 1) { /* test knob: the whole search as one lane runs it (dev_gen.h), no scheduling */
+                            GenWalk gw;
+                            gw.nodes = nodes2; gw.leaves = leaves; gw.entries = entries; gw.chains = chains; gw.n_chains = ga.n_chains;
+                            gw.root = root; gw.first_medium = first_medium;
+                            gw.gx = ga.gx; gw.gy = ga.gy; gw.gz = ga.gz; gw.gR = ga.gR; gw.mnear = ga.mnear; gw.kmin = ga.kmin;
+                            Best b;
+                            const bool hit = gen_world_hit(lsc, gw, ray, rng, b, nullptr);
+                            closest = b.t;
+                            best = GBEST_NONE;
+                            if (hit) {
+                                if (b.kind == HIT_MEDIUM) best = GENT(0, GCHAIN_MEDIUM, (uint32_t)b.prim);
+                                else {
+                                    uint32_t cid = 0;
+                                    for (int k = 1; k < ga.n_chains; k++) if (chains[2 * k] == b.chain_first && chains[2 * k + 1] == b.chain_count) cid = (uint32_t)k;
+                                    best = GENT(b.kind == HIT_QUAD ? 1u : 0u, b.chain_count > 0 ? cid : 0u, (uint32_t)b.prim);
+                                }
+                            }
+                            flags = 0;
+                            state = G_S;
+                        } else
+                        if (!ordinary) state = has_media ? G_M : G_S; /* the scan decides */
+                        else if (root == 0xffffu) state = has_media ? G_M : G_S;
+                        else { node = root & 0x7fffu; state = (root & 0x8000u) ? G_L : G_T; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+/* ---- host side ---- */
+typedef void (*gen_kernel_t)(const GenArgs);
+static gen_kernel_t pick_kernel(int block, bool prims_in_lds) {
+    switch (block) {
+    case 768: return prims_in_lds ? mega_gen_kernel<768, true> : mega_gen_kernel<768, false>;
+    case 512: return prims_in_lds ? mega_gen_kernel<512, true> : mega_gen_kernel<512, false>;
+    case 256: return prims_in_lds ? mega_gen_kernel<256, true> : mega_gen_kernel<256, false>;
+    }
+    return nullptr;
+}
+int mort_gen_blocks_per_cu(int block, bool prims_in_lds, size_t lds_bytes) {
+    gen_kernel_t k = pick_kernel(block, prims_in_lds);
+    if (!k) return 0;
+    if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, block, lds_bytes) != hipSuccess) return 0;
+    return per_cu;
+}
+hipError_t mort_gen_launch(const GenArgs &ga, int block, int grid, size_t lds_bytes, hipStream_t s) {
+    gen_kernel_t k = pick_kernel(block, ga.prims_in_lds != 0);
+    if (!k) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, s, ga);
+    return hipGetLastError();
+}
+hipError_t mort_gen_attributes(int block, bool prims_in_lds, hipFuncAttributes *out) {
+    gen_kernel_t k = pick_kernel(block, prims_in_lds);
+    if (!k) return hipErrorInvalidValue;
+    return hipFuncGetAttributes(out, (const void *)k);
+}

@@ -25,9 +25,11 @@
 #include <vector>
 
 #include "mort_hip.h"
-#include "dev_render.h"
-#include "scene_compile.h"
+#include "dev_pixel.h"
+#include "scene_blob.h"
+#include "seed_host.h"
 #include "mort_internal.h"
+#include "mega_gen.h"
 
 #pragma clang fp contract(off)
 
@@ -39,7 +41,6 @@
 #endif
 extern "C" __global__ void __launch_bounds__(256, MORT_GENERIC_WAVES)
 mega_kernel(const RenderArgs a) {
-    const DScene &sc = a.sc;
     const int lane = threadIdx.x & 63;
     const int wave = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const int tiles_x = (a.width + 7) >> 3;
@@ -49,166 +50,9 @@ mega_kernel(const RenderArgs a) {
     const bool active = (x < a.width) && (ly < a.local_rows);
     if (!active) return;
 
-    const int y = global_row(ly, a.rank, a.nranks, a.rows_per_block);
-    const int lofs = x + ly * a.width;
-
-    Rng rng;
-    {
-        const mort_rng_state st = a.states[lofs];
-        rng.d = st.d; rng.v0 = st.v[0]; rng.v1 = st.v[1]; rng.v2 = st.v[2]; rng.v3 = st.v[3]; rng.v4 = st.v[4];
-        rng.draws = 0;
-    }
-
-    StackEntry stack[MORT_MAX_BOUNCE_LIMIT];
-    unsigned long long ident_mask = 0ull; /* levels whose entry is the identity (dielectric): not stored, see mega_bvh.h */
-    V3 pixel_color = mk(0, 0, 0);
-    const int spp = a.sqrt_spp * a.sqrt_spp;
-    int s = 0, s_i = 0, s_j = 0;
-    int iter = 0;
-    bool fresh = true;
-    uint32_t segments = 0;
-    Ray ray;
-    float ray_time0 = 0.f;
-
-    while (s < spp) {
-        if (fresh) { /* camera.cuh:187-190 */
-            ray = get_ray(a, x, y, rng, s_i, s_j);
-            ray_time0 = ray.tm;
-            iter = 0;
-            fresh = false;
-        }
-        /* ---- one iteration of ray_color's bounce loop (camera.cuh:96-159) ---- */
-        V3 final_value;
-        bool done = false;
-        if (iter >= a.bounce_limit) {
-            final_value = mk(0, 0, 0);
-            done = true;
-        } else {
-            Best best;
-            segments++;
-            if (!world_hit(sc, ray, rng, best)) {
-                final_value = a.background;
-                done = true;
-            } else {
-                HitRec rec;
-                resolve_hit(sc, ray, best, rec);
-                const int mtype = DREF_TYPE(rec.mat), midx = DREF_IDX(rec.mat);
-                if (mtype == MORT_MAT_METAL) { /* materials.cuh:73-84 */
-                    const DMetal m = sc.metal[midx];
-                    V3 reflected = reflect(ray.d, rec.normal);
-                    reflected = vadd(vunit(reflected), vscale(m.fuzz, random_unit_vector(rng)));
-                    ray.o = rec.p; ray.d = reflected; /* time stays r_in.time() */
-                    StackEntry e; e.kx = 1.0f * m.r; e.ky = 1.0f * m.g; e.kz = 1.0f * m.b; e.rp = 1 / 1.0f;
-                    stack[iter] = e;
-                    iter++;
-                } else if (mtype == MORT_MAT_DIELECTRIC) { /* materials.cuh:107-130 */
-                    const DDielectric m = sc.dielectric[midx];
-                    const float refraction_ratio = rec.front_face ? m.inv_ior : m.ior;
-                    const V3 unit_direction = vunit(ray.d);
-                    const float cos_theta = (float)mort_fmin((double)vdot(vneg(unit_direction), rec.normal), 1.0);
-                    const float sin_theta = (float)mort_sqrt(1.0 - (double)(cos_theta * cos_theta));
-                    const bool cant_refract = (double)(refraction_ratio * sin_theta) > 1.0;
-                    V3 direction;
-                    if (cant_refract || reflectance(cos_theta, refraction_ratio) > random_float(rng))
-                        direction = reflect(unit_direction, rec.normal);
-                    else
-                        direction = refract(unit_direction, rec.normal, refraction_ratio);
-                    ray.o = rec.p; ray.d = direction;
-                    ident_mask |= (1ull << iter); /* entry (1,1,1), 1/pdf = 1 */
-                    iter++;
-                } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
-                    /* materials.cuh:38-44,182-188 + camera.cuh:115-145 */
-                    const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
-                    const DLambert m = lamb ? sc.lambert[midx] : sc.isotropic[midx];
-                    const V3 attenuation = lambert_color(sc, m, rec.u, rec.v, rec.p);
-                    Onb uvw;
-                    if (lamb) uvw = onb_from_w(rec.normal);
-                    V3 dir;
-                    bool from_light = false;
-                    if (a.light_type != -1) from_light = random_float(rng) < 0.5; /* mixture_pdf::generate, pdf.cuh:96-103 */
-                    if (from_light) dir = light_random(sc, a.light_type, a.light_idx, rec.p, rng);
-                    else if (lamb) dir = onb_local(uvw, random_cosine_direction(rng));
-                    else dir = random_unit_vector(rng);
-                    /* srec.pdf_ptr->value(dir): cosine_pdf / sphere_pdf (pdf.cuh:29-32,45-49) */
-                    float mat_pdf;
-                    if (lamb) {
-                        const float cosine_theta = vdot(vunit(dir), uvw.w);
-                        mat_pdf = mort_fmaxf(0, (float)((double)cosine_theta / 3.1415926));
-                    } else {
-                        mat_pdf = (float)(1 / (4 * 3.1415926));
-                    }
-                    float pdf = mat_pdf;
-                    if (a.light_type != -1) /* mixture_pdf::value, pdf.cuh:91-93 */
-                        pdf = (float)(0.5 * (double)light_pdf_value(sc, a.light_type, a.light_idx, rec.p, dir) + 0.5 * (double)mat_pdf);
-                    float scattering_pdf; /* materials.cuh:51-55,195-198 */
-                    if (lamb) {
-                        const float cos_theta = vdot(rec.normal, vunit(dir));
-                        scattering_pdf = (cos_theta < 0) ? 0.0f : (float)((double)cos_theta / 3.141592565);
-                    } else {
-                        scattering_pdf = (float)(1 / (4 * 3.1415926));
-                    }
-                    ray.o = rec.p; ray.d = dir; ray.tm = ray_time0; /* ray(rec.p, dir, r.time()) */
-                    StackEntry e;
-                    e.kx = scattering_pdf * attenuation.x; e.ky = scattering_pdf * attenuation.y; e.kz = scattering_pdf * attenuation.z;
-                    e.rp = 1 / pdf;
-                    stack[iter] = e;
-                    iter++;
-                } else { /* diffuse_light (materials.cuh:151-163) or unknown tag: no scatter */
-                    V3 emission = mk(0, 0, 0);
-                    if (mtype == MORT_MAT_DIFFUSE_LIGHT && rec.front_face)
-                        emission = lambert_color(sc, sc.dlight[midx], rec.u, rec.v, rec.p);
-                    final_value = emission;
-                    done = true;
-                }
-            }
-        }
-        if (done) { /* unwind (camera.cuh:165-173) and accumulate (camera.cuh:190) */
-            while (iter > 0) {
-                iter--;
-                if ((ident_mask >> iter) & 1ull) { final_value = vadd(mk(0, 0, 0), final_value); continue; }
-                const StackEntry e = stack[iter];
-                const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
-                final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
-            }
-            ident_mask = 0ull;
-            pixel_color = vadd(pixel_color, final_value);
-            s++;
-            s_i++;
-            if (s_i == a.sqrt_spp) { s_i = 0; s_j++; }
-            fresh = true;
-        }
-    }
-
-    /* camera.cuh:194-207 */
-    pixel_color = vscale(a.pixel_samples_scale, pixel_color);
-    if (pixel_color.x != pixel_color.x) pixel_color.x = 0.0f;
-    if (pixel_color.y != pixel_color.y) pixel_color.y = 0.0f;
-    if (pixel_color.z != pixel_color.z) pixel_color.z = 0.0f;
-    if (a.accum) { a.accum[3 * lofs] = pixel_color.x; a.accum[3 * lofs + 1] = pixel_color.y; a.accum[3 * lofs + 2] = pixel_color.z; }
-    uchar4 out;
-    {
-        float c[3] = {mort_sqrtf(pixel_color.x), mort_sqrtf(pixel_color.y), mort_sqrtf(pixel_color.z)};
-        unsigned char b[3];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            float v = c[k];
-            if (v < 0.0f) v = 0.0f;
-            if (v > 0.999f) v = 0.999f;
-            b[k] = (unsigned char)mort_f2i(256 * v);
-        }
-        out.x = b[0]; out.y = b[1]; out.z = b[2]; out.w = 255;
-    }
-    a.rgba[lofs] = out;
-    if (a.seg_px) a.seg_px[lofs] = segments;
-
-    {
-        mort_rng_state st;
-        st.d = rng.d; st.v[0] = rng.v0; st.v[1] = rng.v1; st.v[2] = rng.v2; st.v[3] = rng.v3; st.v[4] = rng.v4;
-        st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
-        a.states[lofs] = st;
-    }
-    atomicAdd(&a.counters[0], (unsigned long long)segments);
-    atomicAdd(&a.counters[1], (unsigned long long)rng.draws);
+    const PixelTotals t = render_pixel<false>(a, nullptr, x, ly, nullptr); /* dev_pixel.h: the body the host loop runs too */
+    atomicAdd(&a.counters[0], (unsigned long long)t.segments);
+    atomicAdd(&a.counters[1], (unsigned long long)t.draws);
 }
 
 /* ---- seeding: curand_init(seed, subsequence, 0) ---- */
@@ -256,7 +100,6 @@ seed_kernel(const SeedArgs a) {
 
 /* ====================================================================== host */
 
-#define SEQ_LEVELS 32
 
 struct mort_ctx {
     int device = 0;
@@ -287,6 +130,12 @@ struct mort_ctx {
              f_solid = 0, f_checker = 0, fast_bytes = 0;
     int own_nodes = 0, own_leaves = 0;
     bool fast_ok = false;
+    /* unified-tree megakernel (mega_gen.hip): its LDS image and launch constants */
+    void *d_gen = nullptr;
+    uint32_t gen_bytes = 0;
+    GenArgs gen{};
+    bool gen_ok = false;
+    float gen_lo[3] = {0, 0, 0}, gen_hi[3] = {0, 0, 0}, gen_reach = 0;
     int num_cus = 256;
     /* pixel-tile ordering of the BVH megakernel: most expensive tiles first (cost = segments of the previous
      * frame with this geometry, or of a 1-sample probe) so the frame does not end on its longest pixel chains */
@@ -357,33 +206,6 @@ static int global_row_host(const mort_partition &p, int ly) {
 extern "C" int mort_hip_local_rows(const mort_ctx *c, int height) { return c ? local_rows_for(c->part, height) : 0; }
 extern "C" int mort_hip_global_row(const mort_ctx *c, int ly) { return c ? global_row_host(c->part, ly) : 0; }
 
-/* GF(2) 160x160 matrix helpers for the sequence skip (own implementation of the
- * published XORWOW jump: state(n + 2^67 k) = M^k state(n), d unchanged). */
-struct XMat { uint32_t row[160][5]; };
-static void xmat_apply(const XMat &m, const uint32_t v[5], uint32_t out[5]) {
-    uint32_t r[5] = {0, 0, 0, 0, 0};
-    for (int w = 0; w < 5; w++)
-        for (int b = 0; b < 32; b++)
-            if ((v[w] >> b) & 1u) for (int k = 0; k < 5; k++) r[k] ^= m.row[w * 32 + b][k];
-    std::memcpy(out, r, sizeof r);
-}
-static void xmat_square(const XMat &a, XMat &out) { for (int i = 0; i < 160; i++) xmat_apply(a, a.row[i], out.row[i]); }
-static void build_seq_matrices(std::vector<XMat> &seq) {
-    XMat *a = new XMat, *b = new XMat;
-    for (int i = 0; i < 160; i++) {
-        uint32_t v[5] = {0, 0, 0, 0, 0};
-        v[i / 32] = 1u << (i % 32);
-        uint32_t t = v[0] ^ (v[0] >> 2);
-        uint32_t n4 = (v[4] ^ (v[4] << 4)) ^ (t ^ (t << 1));
-        a->row[i][0] = v[1]; a->row[i][1] = v[2]; a->row[i][2] = v[3]; a->row[i][3] = v[4]; a->row[i][4] = n4;
-    }
-    for (int k = 0; k < 67; k++) { xmat_square(*a, *b); std::swap(a, b); }
-    seq.resize(SEQ_LEVELS);
-    seq[0] = *a;
-    for (int k = 1; k < SEQ_LEVELS; k++) { xmat_square(seq[k - 1], *b); xmat_square(*b, seq[k]); }
-    delete a; delete b;
-}
-
 extern "C" int mort_hip_init(int device, mort_ctx **out) {
     if (!out) return MORT_ERR_INVALID;
     *out = nullptr;
@@ -412,7 +234,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     hipSetDevice(c->device);
     quiesce(c);
     hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
-    hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_states); hipFree(c->d_seqmats);
+    hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
     hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states);
     if (c->h_live) hipHostFree(c->h_live);
@@ -435,105 +257,23 @@ extern "C" int mort_hip_set_partition(mort_ctx *c, const mort_partition *p) {
     return MORT_OK;
 }
 
-/* ---- validation of every index the kernels will dereference ---- */
-static bool tex_ok(const mort_world *w, int type, int idx, int depth) {
-    switch (type) {
-    case MORT_TEXTURE_SOLID: return idx >= 0 && idx < w->texs.num_solid_colors;
-    case MORT_TEXTURE_CHECKER: {
-        if (idx < 0 || idx >= w->texs.num_checker_textures || depth > 6) return false;
-        const mort_checker_texture &c = w->texs.host_checker_texture[idx];
-        return tex_ok(w, c.evenTextureType, c.evenTextureIdx, depth + 1) && tex_ok(w, c.oddTextureType, c.oddTextureIdx, depth + 1);
-    }
-    case MORT_TEXTURE_IMAGE: return idx >= 0 && idx < w->texs.num_image_textures;
-    case MORT_TEXTURE_NOISE: return idx >= 0 && idx < w->texs.num_noise_textures;
-    }
-    return true; /* unknown tag: the error pattern, no table access */
-}
-static bool mat_ok(const mort_world *w, int type, int idx) {
-    const mort_world_materials &m = w->mats;
-    switch (type) {
-    case MORT_MAT_LAMBERTIAN: return idx >= 0 && idx < m.num_lambertians && tex_ok(w, m.host_lambertian[idx].texType, m.host_lambertian[idx].texIdx, 0);
-    case MORT_MAT_METAL: return idx >= 0 && idx < m.num_metals;
-    case MORT_MAT_DIELECTRIC: return idx >= 0 && idx < m.num_dielectrics;
-    case MORT_MAT_DIFFUSE_LIGHT: return idx >= 0 && idx < m.num_diffuse_lights && tex_ok(w, m.host_diffuse_light[idx].texType, m.host_diffuse_light[idx].texIdx, 0);
-    case MORT_MAT_ISOTROPIC: return idx >= 0 && idx < m.num_isotropics && tex_ok(w, m.host_isotropic[idx].texType, m.host_isotropic[idx].texIdx, 0);
-    }
-    return true; /* unknown tag: treated as "does not scatter", no table access */
-}
-static int validate_world(const mort_world *w) {
-    const mort_world_objects &o = w->objs;
-    if (o.num_spheres < 0 || o.num_spheres > MORT_NUM_SPHERES || o.num_quads < 0 || o.num_quads > MORT_NUM_QUADS ||
-        o.num_translates < 0 || o.num_translates > MORT_NUM_TRANSLATE || o.num_rotate_y < 0 || o.num_rotate_y > MORT_NUM_ROTATE_Y ||
-        o.num_constant_medium < 0 || o.num_constant_medium > MORT_NUM_CONSTANT_MEDIUM ||
-        o.num_hittable_list < 0 || o.num_hittable_list > MORT_NUM_HITTABLE_LIST || o.num_bvh < 0 || o.num_bvh > MORT_NUM_BVH)
-        return MORT_ERR_CAPACITY;
-    for (int i = 0; i < o.num_spheres; i++) if (!mat_ok(w, o.host_sphere[i].mat_type, o.host_sphere[i].mat_idx)) return MORT_ERR_INVALID;
-    for (int i = 0; i < o.num_quads; i++) if (!mat_ok(w, o.host_quad[i].mat_type, o.host_quad[i].mat_idx)) return MORT_ERR_INVALID;
-    for (int i = 0; i < o.num_constant_medium; i++) if (!mat_ok(w, o.host_constant_medium[i].mat_type, o.host_constant_medium[i].mat_idx)) return MORT_ERR_INVALID;
-    for (int i = 0; i < o.num_hittable_list; i++) if (o.host_hittable_list[i].num_objs < 0 || o.host_hittable_list[i].num_objs > MORT_LIST_MAX_OBJS) return MORT_ERR_INVALID;
-    return MORT_OK;
-}
-
-template <typename T>
-static size_t place(std::vector<unsigned char> &blob, const std::vector<T> &v) {
-    size_t off = (blob.size() + 15) & ~(size_t)15;
-    blob.resize(off + v.size() * sizeof(T) + 16, 0); /* 16 B tail so empty arrays still get distinct, valid addresses */
-    if (!v.empty()) std::memcpy(blob.data() + off, v.data(), v.size() * sizeof(T));
-    return off;
-}
-
 extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     if (!c || !w) return MORT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, quiesce(c));
     c->cost_key = 0; c->world_serial++;
-    int st = validate_world(w);
+    int st;
+    SceneBlob sb;
+    st = build_scene_blob(w, sb);
     if (st != MORT_OK) return st;
-    mortc::Compiler comp;
-    comp.w = w;
-    comp.run();
-    if (comp.out.status != MORT_OK) return comp.out.status;
-    mortc::Compiled &o = comp.out;
-    if (o.inverted_box) return MORT_ERR_UNSUPPORTED; /* slab_hit orders planes with min/max: needs min <= max boxes */
-
-    std::vector<unsigned char> blob;
-    const size_t o_items = place(blob, o.items), o_sub = place(blob, o.subitems), o_nodes = place(blob, o.nodes);
-    const size_t o_sph = place(blob, o.spheres), o_quads = place(blob, o.quads), o_xf = place(blob, o.xforms);
-    const size_t o_media = place(blob, o.media);
-    const size_t o_lamb = place(blob, o.lambert), o_metal = place(blob, o.metal), o_diel = place(blob, o.dielectric);
-    const size_t o_dl = place(blob, o.dlight), o_iso = place(blob, o.isotropic);
-    const size_t o_solid = place(blob, o.solid), o_chk = place(blob, o.checker), o_img = place(blob, o.image);
-    const size_t hot_bytes = (blob.size() + 15) & ~(size_t)15;
-    const size_t o_wsph = place(blob, o.wspheres), o_wquads = place(blob, o.wquads);
-    const size_t o_lt = place(blob, o.list_types), o_li = place(blob, o.list_idxs);
-    const size_t o_noise = place(blob, o.noise), o_tex = place(blob, o.texels);
-
+    const mortc::Compiled &o = sb.comp;
     void *d = nullptr;
-    HIPCHK(c, hipMalloc(&d, blob.size()));
-    hipError_t e = hipMemcpy(d, blob.data(), blob.size(), hipMemcpyHostToDevice);
+    HIPCHK(c, hipMalloc(&d, sb.bytes.size()));
+    hipError_t e = hipMemcpy(d, sb.bytes.data(), sb.bytes.size(), hipMemcpyHostToDevice);
     if (e != hipSuccess) { hipFree(d); return hip_fail(c, e, "hipMemcpy(scene)"); }
     if (c->d_scene) hipFree(c->d_scene);
     c->d_scene = d;
-    const unsigned char *base = (const unsigned char *)d;
-    DScene &s = c->sc;
-    std::memset(&s, 0, sizeof s);
-    s.items = (const DItem *)(base + o_items); s.n_items = (int)o.items.size();
-    s.subitems = (const DItem *)(base + o_sub); s.n_subitems = (int)o.subitems.size();
-    s.nodes = (const DBvhNode *)(base + o_nodes); s.n_nodes = (int)o.nodes.size();
-    s.spheres = (const DSphere *)(base + o_sph); s.n_spheres = (int)o.spheres.size();
-    s.quads = (const DQuad *)(base + o_quads); s.n_quads = (int)o.quads.size();
-    s.xforms = (const DXform *)(base + o_xf); s.n_xforms = (int)o.xforms.size();
-    s.neg_inv_density = (const double *)(base + o_media); s.n_media = (int)o.media.size();
-    s.lambert = (const DLambert *)(base + o_lamb); s.metal = (const DMetal *)(base + o_metal);
-    s.dielectric = (const DDielectric *)(base + o_diel);
-    s.dlight = (const DLambert *)(base + o_dl); s.isotropic = (const DLambert *)(base + o_iso);
-    s.solid = (const DSolid *)(base + o_solid); s.checker = (const DChecker *)(base + o_chk); s.image = (const DImage *)(base + o_img);
-    s.texels = base + o_tex; s.noise = (const float *)(base + o_noise);
-    s.wspheres = (const DSphere *)(base + o_wsph); s.wquads = (const DQuad *)(base + o_wquads);
-    s.list_types = (const int *)(base + o_lt); s.list_idxs = (const int *)(base + o_li);
-    for (int i = 0; i < MORT_NUM_HITTABLE_LIST; i++) { s.list_first[i] = o.list_first[i]; s.list_count[i] = o.list_count[i]; }
-    s.blob_bytes = (uint32_t)hot_bytes;
-    s.lds_bytes = (uint32_t)hot_bytes;
+    scene_view(sb, (const unsigned char *)d, c->sc);
     c->list_types = o.list_types; c->list_idxs = o.list_idxs;
     for (int i = 0; i < MORT_NUM_HITTABLE_LIST; i++) { c->list_first[i] = o.list_first[i]; c->list_count[i] = o.list_count[i]; }
     c->n_wspheres = (int)o.wspheres.size(); c->n_wquads = (int)o.wquads.size(); c->n_lists = w->objs.num_hittable_list;
@@ -555,6 +295,40 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
             c->fast_bytes = (uint32_t)fb.size();
             c->own_nodes = (int)o.own_nodes.size(); c->own_leaves = (int)o.own_leaves.size();
             c->fast_ok = true;
+        }
+    }
+    /* unified-tree megakernel: LDS image = tree + every small table (+ the primitives when they fit) */
+    c->gen_ok = false;
+    if (c->d_gen) { hipFree(c->d_gen); c->d_gen = nullptr; }
+    if (o.g_ok && !std::getenv("MORT_NO_GEN")) {
+        std::vector<unsigned char> gb;
+        GenArgs g;
+        std::memset(&g, 0, sizeof g);
+        g.o_nodes = (uint32_t)place(gb, o.g_nodes); g.o_leaves = (uint32_t)place(gb, o.g_leaves); g.o_entries = (uint32_t)place(gb, o.g_entries);
+        g.o_chains = (uint32_t)place(gb, o.g_chains); g.o_xforms = (uint32_t)place(gb, o.xforms);
+        g.o_items = (uint32_t)place(gb, o.items); g.o_subitems = (uint32_t)place(gb, o.subitems); g.o_media = (uint32_t)place(gb, o.media);
+        g.o_lambert = (uint32_t)place(gb, o.lambert); g.o_metal = (uint32_t)place(gb, o.metal); g.o_diel = (uint32_t)place(gb, o.dielectric);
+        g.o_dlight = (uint32_t)place(gb, o.dlight); g.o_iso = (uint32_t)place(gb, o.isotropic);
+        g.o_solid = (uint32_t)place(gb, o.solid); g.o_checker = (uint32_t)place(gb, o.checker); g.o_image = (uint32_t)place(gb, o.image);
+        const size_t prim_bytes = o.spheres.size() * sizeof(DSphere) + o.quads.size() * sizeof(DQuad) + o.wspheres.size() * sizeof(DSphere) +
+                                  o.wquads.size() * sizeof(DQuad) + (o.list_types.size() + o.list_idxs.size()) * sizeof(int) + 6 * 32;
+        if (gb.size() + prim_bytes <= 48 * 1024) {
+            g.prims_in_lds = 1;
+            g.o_spheres = (uint32_t)place(gb, o.spheres); g.o_quads = (uint32_t)place(gb, o.quads);
+            g.o_wspheres = (uint32_t)place(gb, o.wspheres); g.o_wquads = (uint32_t)place(gb, o.wquads);
+            g.o_ltypes = (uint32_t)place(gb, o.list_types); g.o_lidxs = (uint32_t)place(gb, o.list_idxs);
+        }
+        gb.resize((gb.size() + 15) & ~(size_t)15, 0);
+        if (gb.size() <= 100 * 1024) {
+            HIPCHK(c, hipMalloc(&c->d_gen, gb.size()));
+            HIPCHK(c, hipMemcpy(c->d_gen, gb.data(), gb.size(), hipMemcpyHostToDevice));
+            c->gen_bytes = (uint32_t)gb.size();
+            g.root = o.g_root; g.first_medium = o.g_first_medium; g.n_chains = (int)(o.g_chains.size() / 2);
+            g.gx = o.g_c[0]; g.gy = o.g_c[1]; g.gz = o.g_c[2]; g.gR = o.g_R; g.mnear = o.g_mnear; g.kmin = o.g_kmin;
+            c->gen = g;
+            for (int k = 0; k < 3; k++) { c->gen_lo[k] = o.g_lo[k]; c->gen_hi[k] = o.g_hi[k]; }
+            c->gen_reach = o.g_reach;
+            c->gen_ok = true;
         }
     }
     c->have_world = true;
@@ -588,13 +362,8 @@ extern "C" int mort_hip_rng_seed(mort_ctx *c, uint64_t seed, int width, int heig
     a.states = c->d_states; a.mats = c->d_seqmats; a.levels = SEQ_LEVELS;
     a.width = width; a.local_rows = c->rng_local_rows;
     a.rank = c->part.rank; a.nranks = c->part.nranks; a.rows_per_block = c->part.rows_per_block;
-    /* curand_init seed scramble (cuRAND XORWOW, curand_kernel.h) */
-    const uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u;
-    const uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
-    const uint32_t t0 = 1099087573u * s0;
-    const uint32_t t1 = 2591861531u * s1;
-    a.d0 = 6615241u + t1 + t0;
-    a.v0 = 123456789u + t0; a.v1 = 362436069u ^ t0; a.v2 = 521288629u + t1; a.v3 = 88675123u ^ t1; a.v4 = 5783321u + t0;
+    const SeedWords sw = seed_scramble(seed);
+    a.d0 = sw.d; a.v0 = sw.v[0]; a.v1 = sw.v[1]; a.v2 = sw.v[2]; a.v3 = sw.v[3]; a.v4 = sw.v[4];
     const int n = width * c->rng_local_rows;
     if (n > 0) {
         hipLaunchKernelGGL(seed_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
@@ -629,7 +398,6 @@ extern "C" int mort_hip_rng_store(mort_ctx *c, mort_rng_state *states, int width
     return MORT_OK;
 }
 
-static V3 to_v3(const mort_vec3 &v) { V3 r; r.x = v.e[0]; r.y = v.e[1]; r.z = v.e[2]; return r; }
 
 static int check_light(const mort_ctx *c, int type, int idx) {
     if (type == -1) return MORT_OK;
@@ -723,6 +491,61 @@ static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera 
     return MORT_OK;
 }
 
+/* ---- tile order of the state-machine megakernels: most expensive 8x8 tiles first (cost = segments per tile in the
+ * previous frame of this world / view / partition, or in a one-sample probe on a scratch copy of the streams), so a frame
+ * does not end on its longest pixel chains.  Everything is queued on `s`; nothing waits on the host. ---- */
+template <typename ProbeFn>
+static int prepare_tile_order(mort_ctx *c, const mort_camera *cam, const RenderArgs &a, FastArgs &fa, int tiles, int grid, int FB,
+                              bool chain_bound, hipStream_t s, ProbeFn launch_probe) {
+    const int W = a.width, H = a.height;
+    if (c->tile_cap < (size_t)tiles) {
+        hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
+        c->d_tile_cost = c->d_tile_order = c->d_tile_keys = c->d_tile_iota = nullptr; c->d_sort_tmp = nullptr;
+        c->tile_cap = 0; c->sort_tmp_bytes = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_tile_cost, (size_t)tiles * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc((void **)&c->d_tile_order, (size_t)tiles * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc((void **)&c->d_tile_keys, (size_t)tiles * sizeof(unsigned)));
+        HIPCHK(c, hipMalloc((void **)&c->d_tile_iota, (size_t)tiles * sizeof(unsigned)));
+        c->sort_tmp_bytes = mort_tile_sort_temp_bytes(tiles);
+        HIPCHK(c, hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes ? c->sort_tmp_bytes : 16));
+        c->tile_cap = (size_t)tiles;
+        c->cost_key = 0;
+    }
+    /* the costs belong to one (world, image geometry, partition, view): FNV-1a over all of it */
+    unsigned long long key = 1469598103934665603ull;
+    auto mix = [&key](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ull; } };
+    { const int g[9] = {W, H, a.local_rows, a.rank, a.nranks, a.rows_per_block, cam->bounce_limit, (int)c->world_serial, a.light_type * 65536 + a.light_idx}; mix(g, sizeof g); }
+    mix(&a.center, sizeof a.center); mix(&a.pixel00, sizeof a.pixel00); mix(&a.du, sizeof a.du); mix(&a.dv, sizeof a.dv);
+    mix(&a.defocus_angle, sizeof a.defocus_angle);
+    if (key == 0) key = 1;
+    if (c->cost_key != key) { /* no history for this view: one-sample probe on a scratch copy of the streams */
+        const size_t npx = (size_t)W * (size_t)a.local_rows;
+        if (c->probe_cap < npx) {
+            if (c->d_probe_states) { hipFree(c->d_probe_states); c->d_probe_states = nullptr; c->probe_cap = 0; }
+            HIPCHK(c, hipMalloc((void **)&c->d_probe_states, npx * sizeof(mort_rng_state)));
+            c->probe_cap = npx;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_probe_states, c->d_states, npx * sizeof(mort_rng_state), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
+        FastArgs pa = fa;
+        pa.r.states = c->d_probe_states; pa.r.sqrt_spp = 1; pa.r.recip_sqrt_spp = 1.0f; pa.r.pixel_samples_scale = 1.0f;
+        pa.r.accum = nullptr; pa.r.seg_px = nullptr;
+        pa.tile_order = nullptr; pa.tile_cost = c->d_tile_cost;
+        HIPCHK(c, launch_probe(pa));
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
+        c->cost_key = key;
+    }
+    /* order = argsort(cost, descending, equal costs by index), on the device and on this stream */
+    HIPCHK(c, mort_tile_sort_desc(c->d_tile_cost, c->d_tile_keys, c->d_tile_iota, c->d_tile_order, c->d_sort_tmp, c->sort_tmp_bytes, tiles, s));
+    HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
+    fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost;
+    fa.gen_tiles = grid * (FB / 64); /* one tile's worth of slots per wave in flight */
+    fa.spread_shift = chain_bound ? 0 : 6; /* measured: whole tiles while lanes refill several times, single pixels otherwise */
+    { const char *sp = std::getenv("MORT_SPREAD_SHIFT"); if (sp) fa.spread_shift = std::atoi(sp); }
+    if (fa.spread_shift >= 6 || fa.spread_shift < 0) fa.gen_tiles = 0;
+    return MORT_OK;
+}
+
 /* d_segpx: per-pixel segment counts for the packed owned rows, or null.  Only mort_hip_render passes one (sized for
  * THIS image and partition); the public device entry never does, so a buffer left over from an earlier, smaller
  * render can not be written past its end. */
@@ -746,19 +569,14 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
     RenderArgs a;
     std::memset(&a, 0, sizeof a);
     a.sc = c->sc;
-    a.width = W; a.height = H;
-    a.sqrt_spp = cam->sqrt_spp; a.bounce_limit = cam->bounce_limit;
-    a.recip_sqrt_spp = cam->recip_sqrt_spp; a.pixel_samples_scale = cam->pixel_samples_scale;
-    a.background = to_v3(cam->background); a.center = to_v3(cam->center); a.pixel00 = to_v3(cam->pixel00_loc);
-    a.du = to_v3(cam->pixel_delta_u); a.dv = to_v3(cam->pixel_delta_v);
-    a.defocus_u = to_v3(cam->defocus_disk_u); a.defocus_v = to_v3(cam->defocus_disk_v);
-    a.defocus_angle = cam->defocus_angle;
-    a.light_type = cam->light_obj_type; a.light_idx = cam->light_obj_idx;
+    render_args_camera(a, cam);
     a.rank = c->part.rank; a.nranks = c->part.nranks; a.rows_per_block = c->part.rows_per_block;
     a.local_rows = c->rng_local_rows;
     a.states = c->d_states;
     a.rgba = (uchar4 *)d_rgba; a.accum = (float *)d_accum; a.seg_px = d_segpx;
     a.counters = c->d_counters;
+    a.debug_lofs = -1;
+    { const char *dp = std::getenv("MORT_DEBUG_PIXEL"); if (dp) a.debug_lofs = std::atoi(dp); }
 
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s));
     const int tiles = ((W + 7) / 8) * ((a.local_rows + 7) / 8);
@@ -768,7 +586,19 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
     const bool use_fast = c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 32768 && cam->bounce_limit >= 1 &&
                           W < 65536 && H < 32768 &&
                           !(force && force[0] == '1');
-    int lds_bytes_used = 0;
+    /* the unified-tree megakernel (mega_gen.hip): worlds without reference BVHs; the camera must lie where the tree's
+     * pads were sized for (scene_compile.h build_unified) */
+    bool use_gen = c->gen_ok && !use_fast && cam->sqrt_spp >= 1 && cam->sqrt_spp < 32768 && cam->bounce_limit >= 1 && W < 65536 && H < 32768 &&
+                   !(force && force[0] == '1');
+    if (use_gen) {
+        const float rad = std::fabs(cam->defocus_disk_u.e[0]) + std::fabs(cam->defocus_disk_u.e[1]) + std::fabs(cam->defocus_disk_u.e[2]) +
+                          std::fabs(cam->defocus_disk_v.e[0]) + std::fabs(cam->defocus_disk_v.e[1]) + std::fabs(cam->defocus_disk_v.e[2]);
+        for (int k = 0; k < 3; k++) {
+            const float v = cam->center.e[k];
+            if (!(v - rad >= c->gen_lo[k] - c->gen_reach && v + rad <= c->gen_hi[k] + c->gen_reach)) use_gen = false;
+        }
+    }
+    int lds_bytes_used = 0, gen_block_used = 0;
     const void *fast_kernel_used = nullptr;
     char kname[64] = "mega_kernel";
     if (mode == MORT_MODE_WAVE) {
@@ -843,59 +673,67 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         fast_kernel_used = (const void *)kern;
         std::snprintf(kname, sizeof kname, "mega_bvh_kernel<%d, false, %s>", FB, chain_bound ? "true" : "false");
         /* ---- tile order: expensive tiles first ---- */
-        const bool want_order = !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid;
-        if (want_order) {
-            if (c->tile_cap < (size_t)tiles) {
-                hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
-                c->d_tile_cost = c->d_tile_order = c->d_tile_keys = c->d_tile_iota = nullptr; c->d_sort_tmp = nullptr;
-                c->tile_cap = 0; c->sort_tmp_bytes = 0;
-                HIPCHK(c, hipMalloc((void **)&c->d_tile_cost, (size_t)tiles * sizeof(unsigned)));
-                HIPCHK(c, hipMalloc((void **)&c->d_tile_order, (size_t)tiles * sizeof(unsigned)));
-                HIPCHK(c, hipMalloc((void **)&c->d_tile_keys, (size_t)tiles * sizeof(unsigned)));
-                HIPCHK(c, hipMalloc((void **)&c->d_tile_iota, (size_t)tiles * sizeof(unsigned)));
-                c->sort_tmp_bytes = mort_tile_sort_temp_bytes(tiles);
-                HIPCHK(c, hipMalloc(&c->d_sort_tmp, c->sort_tmp_bytes ? c->sort_tmp_bytes : 16));
-                c->tile_cap = (size_t)tiles;
-                c->cost_key = 0;
-            }
-            /* the costs belong to one (world, image geometry, partition, view): FNV-1a over all of it */
-            unsigned long long key = 1469598103934665603ull;
-            auto mix = [&key](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ull; } };
-            { const int g[8] = {W, H, a.local_rows, a.rank, a.nranks, a.rows_per_block, cam->bounce_limit, (int)c->world_serial}; mix(g, sizeof g); }
-            mix(&a.center, sizeof a.center); mix(&a.pixel00, sizeof a.pixel00); mix(&a.du, sizeof a.du); mix(&a.dv, sizeof a.dv);
-            mix(&a.defocus_angle, sizeof a.defocus_angle);
-            if (key == 0) key = 1;
-            if (c->cost_key != key) { /* no history for this view: one-sample probe on a scratch copy of the streams */
-                const size_t npx = (size_t)W * (size_t)a.local_rows;
-                if (c->probe_cap < npx) {
-                    if (c->d_probe_states) { hipFree(c->d_probe_states); c->d_probe_states = nullptr; c->probe_cap = 0; }
-                    HIPCHK(c, hipMalloc((void **)&c->d_probe_states, npx * sizeof(mort_rng_state)));
-                    c->probe_cap = npx;
-                }
-                HIPCHK(c, hipMemcpyAsync(c->d_probe_states, c->d_states, npx * sizeof(mort_rng_state), hipMemcpyDeviceToDevice, s));
-                HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
-                FastArgs pa = fa;
-                pa.r.states = c->d_probe_states; pa.r.sqrt_spp = 1; pa.r.recip_sqrt_spp = 1.0f; pa.r.pixel_samples_scale = 1.0f;
-                pa.r.accum = nullptr; pa.r.seg_px = nullptr;
-                pa.tile_order = nullptr; pa.tile_cost = c->d_tile_cost;
-                HIPCHK(c, hipFuncSetAttribute((const void *)kern_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        if (!std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
+            int st_o = prepare_tile_order(c, cam, a, fa, tiles, grid, FB, chain_bound, s, [&](const FastArgs &pa) {
+                hipError_t e_ = hipFuncSetAttribute((const void *)kern_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e_ != hipSuccess) return e_;
                 hipLaunchKernelGGL(kern_probe, dim3(grid), dim3(FB), lds_bytes, s, pa);
-                HIPCHK(c, hipGetLastError());
-                HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
-                c->cost_key = key;
-            }
-            /* order = argsort(cost, descending, equal costs by index), on the device and on this stream */
-            HIPCHK(c, mort_tile_sort_desc(c->d_tile_cost, c->d_tile_keys, c->d_tile_iota, c->d_tile_order, c->d_sort_tmp, c->sort_tmp_bytes, tiles, s));
-            HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
-            fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost;
-            fa.gen_tiles = grid * (FB / 64); /* one tile's worth of slots per wave in flight */
-            fa.spread_shift = chain_bound ? 0 : 6; /* measured: whole tiles while lanes refill several times, single pixels otherwise */
-            { const char *sp = std::getenv("MORT_SPREAD_SHIFT"); if (sp) fa.spread_shift = std::atoi(sp); }
-            if (fa.spread_shift >= 6 || fa.spread_shift < 0) fa.gen_tiles = 0;
+                return hipGetLastError();
+            });
+            if (st_o != MORT_OK) return st_o;
             if (stats) HIPCHK(c, hipEventRecord(c->ev0, s)); /* time the frame itself; ordering upkeep is reported by wall-clock benches */
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FB), lds_bytes, s, fa);
         HIPCHK(c, hipGetLastError());
+    } else if (blocks > 0 && use_gen) {
+        GenArgs ga;
+        std::memset(&ga, 0, sizeof ga);
+        ga = c->gen; /* LDS image offsets, root, far-ray constants (upload_world) */
+        FastArgs &fa = ga.f;
+        fa.r = a;
+        fa.hot_src = (const unsigned char *)c->d_gen; fa.hot_bytes = c->gen_bytes;
+        fa.next_q = (unsigned int *)(c->d_counters + 2);
+        fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
+        const long long lanes_wanted = (long long)tiles * 64;
+        int FB = 768;
+        { const char *fb_env = std::getenv("MORT_GEN_BLOCK_SIZE");
+          if (fb_env) FB = std::atoi(fb_env);
+          else { FB = 256; const int cand[3] = {768, 512, 256}; for (int k = 0; k < 3; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; } } }
+        if (FB != 768 && FB != 512 && FB != 256) FB = 256;
+        fa.th_s = MORT_TH_S; fa.th_l = MORT_TH_L; fa.t_keep = MORT_T_KEEP; ga.th_m = 24;
+        { const char *lw = std::getenv("MORT_GEN_LANE_WALK"); ga.lane_walk = lw ? std::atoi(lw) : 0; }
+        { const char *th = std::getenv("MORT_GEN_THRESHOLDS"); /* "s,l,k,m" */
+          if (th) { int s_ = 0, l_ = 0, k_ = 0, m_ = 0; if (std::sscanf(th, "%d,%d,%d,%d", &s_, &l_, &k_, &m_) == 4) { fa.th_s = s_; fa.th_l = l_; fa.t_keep = k_; ga.th_m = m_; } } }
+        const uint32_t tstack_off = (c->gen_bytes + 15u) & ~15u;
+        const uint32_t stack_off = tstack_off + (uint32_t)MORT_OWN_STACK * (uint32_t)FB * 2u;
+        fa.off_tstack = tstack_off;
+        const int groups_per_cu = FB == 512 ? 1 : 768 / FB;
+        int dl = (int)(((160u * 1024u - 256u) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
+        if (dl > 12) dl = 12;
+        if (dl < 0) dl = 0;
+        { const char *de = std::getenv("MORT_GEN_DL"); if (de && std::atoi(de) < dl) dl = std::atoi(de); }
+        fa.off_stack = stack_off; fa.stack_lds_depth = dl;
+        const size_t lds_bytes = (size_t)stack_off + (size_t)dl * FB * 16;
+        int per_cu = mort_gen_blocks_per_cu(FB, ga.prims_in_lds != 0, lds_bytes);
+        if (per_cu < 1) per_cu = 1;
+        int grid = c->num_cus * per_cu;
+        const int want_blocks = (int)((lanes_wanted + FB - 1) / FB);
+        if (grid > want_blocks) grid = want_blocks;
+        if (grid < 1) grid = 1;
+        lds_bytes_used = (int)lds_bytes;
+        gen_block_used = FB;
+        std::snprintf(kname, sizeof kname, "mega_gen_kernel<%d, %s>", FB, ga.prims_in_lds ? "true" : "false");
+        if (!std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
+            int st_o = prepare_tile_order(c, cam, a, fa, tiles, grid, FB, false, s, [&](const FastArgs &pa) {
+                GenArgs pg = ga;
+                pg.f = pa;
+                pg.probe = 1;
+                return mort_gen_launch(pg, FB, grid, lds_bytes, s);
+            });
+            if (st_o != MORT_OK) return st_o;
+            if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
+        }
+        HIPCHK(c, mort_gen_launch(ga, FB, grid, lds_bytes, s));
     } else if (blocks > 0) {
         hipLaunchKernelGGL(mega_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, s, a);
         HIPCHK(c, hipGetLastError());
@@ -944,20 +782,21 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         for (int k = 0; k < 32; k++) { cnt[0] += cnt[32 + 2 * k]; cnt[1] += cnt[33 + 2 * k]; } /* BVH megakernel: per-workgroup slots */
         stats->segments = cnt[0];
         stats->rng_draws = cnt[1];
-        stats->reference_walks = (use_fast && mode != MORT_MODE_WAVE) ? cnt[3] : 0;
+        stats->reference_walks = ((use_fast || use_gen) && mode != MORT_MODE_WAVE) ? cnt[3] : 0;
         stats->pixels = (uint64_t)W * (uint64_t)a.local_rows;
         stats->eff_samples = stats->pixels * (uint64_t)(cam->sqrt_spp * cam->sqrt_spp);
         stats->algorithmic_hbm_bytes = stats->pixels * (uint64_t)(100 + (d_accum ? 12 : 0));
-        stats->scene_in_lds = (use_fast || mode == MORT_MODE_WAVE) ? 1 : 0;
+        stats->scene_in_lds = (use_fast || use_gen || mode == MORT_MODE_WAVE) ? 1 : 0;
         if (mode == MORT_MODE_WAVE) stats->algorithmic_hbm_bytes += 240ull * stats->segments; /* wave_bvh.h: per-segment record traffic */
         stats->local_rows = a.local_rows;
         std::memcpy(stats->kernel_name, kname, sizeof stats->kernel_name);
         hipFuncAttributes fattr;
         const void *kf = mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
                          : fast_kernel_used;
-        if (hipFuncGetAttributes(&fattr, kf) == hipSuccess) {
+        const bool gen_ran = use_gen && mode != MORT_MODE_WAVE && gen_block_used > 0;
+        if ((gen_ran ? mort_gen_attributes(gen_block_used, c->gen.prims_in_lds != 0, &fattr) : hipFuncGetAttributes(&fattr, kf)) == hipSuccess) {
             stats->kernel_vgprs = fattr.numRegs;
-            stats->kernel_lds_bytes = use_fast ? lds_bytes_used : (int)fattr.sharedSizeBytes;
+            stats->kernel_lds_bytes = (use_fast || gen_ran) ? lds_bytes_used : (int)fattr.sharedSizeBytes;
         }
     }
     return MORT_OK;

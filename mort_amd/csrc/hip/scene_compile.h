@@ -46,6 +46,21 @@ struct Compiled {
     std::vector<DNode2> own_nodes;
     std::vector<DBvhNode> own_leaves;
     int own_depth = 0;
+    /* this build's UNIFIED tree over every solid primitive of a world without reference BVHs (mega_gen.hip):
+     * see build_unified() */
+    bool g_ok = false;
+    std::vector<DNode2> g_nodes;
+    std::vector<uint32_t> g_leaves;  /* first entry | count << 24 */
+    std::vector<uint32_t> g_entries; /* GENT(kind, chain id, index in spheres / quads) */
+    std::vector<int> g_chains;       /* chain id -> (first, count) in xforms; id 0 = no transform */
+    uint32_t g_root = 0xffffu;       /* child reference of the root (0xffff: no solid primitive at all) */
+    int g_first_medium = 0;          /* items[g_first_medium ..) are the constant media, tested after the tree */
+    int g_depth = 0;
+    float g_lo[3] = {0, 0, 0}, g_hi[3] = {0, 0, 0}; /* bounding box of the solids */
+    float g_reach = 0;               /* ray origins must stay within this distance of that box (pads are sized for it) */
+    /* spheres seen from far away: a ray whose origin is further than g_mnear - g_R from g_c widens its own error band
+     * by g_kmin * (|o - g_c| + g_R)^2 world units (mega_gen.hip ray setup) */
+    float g_c[3] = {0, 0, 0}, g_R = 0, g_mnear = 0, g_kmin = 0;
 };
 
 static inline DSphere to_dsphere(const mort_sphere &s) {
@@ -430,6 +445,212 @@ struct Compiler {
         out.own_depth = ob.max_depth_seen + 1;
     }
 
+    /* ---- this build's UNIFIED tree (mega_gen.hip, wave_gen.hip).  A world without reference BVHs is a linear
+     * scan over all its solid primitives (world.cuh:122-168; instances and lists flattened into runs that share a
+     * transform chain) followed by its constant media.  The scan's result is: the primitive whose OWN hit test
+     * succeeds with the smallest t, equal t -> the one scanned last (each test accepts t <= closest_so_far, and a
+     * primitive's accepted root does not depend on t_max: dev_trace.h run_accel).  So any traversal that sees every
+     * primitive whose own t is <= the final closest gives the same answer, exact ties being resolved by the scan
+     * itself (the kernels fall back to it when two accepted hits have equal t).
+     *
+     * Boxes.  A sphere / quad test that accepts a root t_c places the point P(t_c) of the ray (in the primitive's
+     * frame) within  delta  of the primitive:  quads: the computed point lies in the parallelogram up to the
+     * rounding of alpha / beta and off its plane by |t_c - t| |n.d| <= a few ulp of M = the largest coordinate
+     * involved;  spheres: the accepted discriminant is >= 0 up to its rounding error <= 10 u a M^2 (u = 2^-24), so
+     * P(t_c) is at most  5 u M^2 / r  outside the sphere.  With M <= reach (ray origins are the camera centre and
+     * points on / in scene objects) every primitive's box is padded by more than its delta, in its own frame, then
+     * carried to world space (the 8 corners through the chain, in double) and padded again for the fp32 rounding
+     * of the device's ray transform.  Hence: own t_c accepted  =>  the ray is inside the world box at parameter
+     * t_c  =>  (exact) entry parameter <= t_c.  The device prunes a box only if the ray misses it by more than the
+     * fp32 error band of its slab evaluation, or enters it later than closest_so_far by more than that band.
+     * Media are evaluated after the tree with the final closest_so_far, as the scan does (their RNG draw depends
+     * on it); a world with a solid scanned AFTER a medium is not given a unified tree. ---- */
+    struct GPrim { int kind, idx, cf, cc, chain_id; Box wb; };
+    static void chain_to_world(const std::vector<DXform> &xf, int cf, int cc, double p[3]) {
+        for (int k = cc - 1; k >= 0; k--) { /* unapply_chain (dev_trace.h), in double */
+            const DXform &x = xf[cf + k];
+            if (x.kind == XF_TRANSLATE) { p[0] += x.a; p[1] += x.b; p[2] += x.c; }
+            else { const double st = x.a, ct = x.b, px = p[0], pz = p[2]; p[0] = ct * px + st * pz; p[2] = -st * px + ct * pz; }
+        }
+    }
+    uint32_t gen_emit(std::vector<GPrim> &pr, std::vector<int> &ids, int lo, int hi, int depth, Box &box_out) {
+        const int n = hi - lo;
+        Box u = pr[ids[lo]].wb;
+        for (int i = lo + 1; i < hi; i++) u = box_union(u, pr[ids[i]].wb);
+        box_out = u;
+        if (depth > out.g_depth) out.g_depth = depth;
+        const int left = MORT_OWN_MAX_DEPTH - depth; /* node levels left below this point */
+        if (n <= MORT_GEN_LEAF_MAX || left <= 0) {
+            if (n > 255) { fail(MORT_ERR_CAPACITY); return 0xffffu; }
+            const size_t leaf = out.g_leaves.size();
+            out.g_leaves.push_back((uint32_t)out.g_entries.size() | ((uint32_t)n << 24));
+            for (int i = lo; i < hi; i++) {
+                const GPrim &g = pr[ids[i]];
+                out.g_entries.push_back(GENT(g.kind == ITEM_QUADS ? 1u : 0u, (uint32_t)g.chain_id, (uint32_t)g.idx));
+            }
+            return 0x8000u | (uint32_t)leaf;
+        }
+        /* both halves must fit below: at most LEAF_MAX * 2^(left-1) primitives each */
+        const long long cap = (long long)MORT_GEN_LEAF_MAX << (left - 1 < 40 ? left - 1 : 40);
+        double best = 1e300; int bax = 0, bsplit = n / 2;
+        std::vector<int> tmp(n);
+        std::vector<double> ra(n);
+        for (int ax = 0; ax < 3; ax++) {
+            std::copy(ids.begin() + lo, ids.begin() + hi, tmp.begin());
+            std::stable_sort(tmp.begin(), tmp.end(), [&](int a, int b) { return pr[a].wb.lo[ax] + pr[a].wb.hi[ax] < pr[b].wb.lo[ax] + pr[b].wb.hi[ax]; });
+            Box r = pr[tmp[n - 1]].wb; ra[n - 1] = box_area(r);
+            for (int i = n - 2; i >= 0; i--) { r = box_union(r, pr[tmp[i]].wb); ra[i] = box_area(r); }
+            Box l = pr[tmp[0]].wb;
+            for (int i = 1; i < n; i++) {
+                if (i <= cap && n - i <= cap) {
+                    const double c = box_area(l) * i + ra[i] * (n - i);
+                    if (c < best) { best = c; bax = ax; bsplit = i; }
+                }
+                l = box_union(l, pr[tmp[i]].wb);
+            }
+        }
+        std::stable_sort(ids.begin() + lo, ids.begin() + hi, [&](int a, int b) { return pr[a].wb.lo[bax] + pr[a].wb.hi[bax] < pr[b].wb.lo[bax] + pr[b].wb.hi[bax]; });
+        const size_t me = out.g_nodes.size();
+        out.g_nodes.push_back(DNode2{});
+        Box b0, b1;
+        const uint32_t c0 = gen_emit(pr, ids, lo, lo + bsplit, depth + 1, b0);
+        const uint32_t c1 = gen_emit(pr, ids, lo + bsplit, hi, depth + 1, b1);
+        DNode2 nd;
+        nd.x0min = b0.lo[0]; nd.x0max = b0.hi[0]; nd.y0min = b0.lo[1]; nd.y0max = b0.hi[1]; nd.z0min = b0.lo[2]; nd.z0max = b0.hi[2];
+        nd.x1min = b1.lo[0]; nd.x1max = b1.hi[0]; nd.y1min = b1.lo[1]; nd.y1max = b1.hi[1]; nd.z1min = b1.lo[2]; nd.z1max = b1.hi[2];
+        nd.child0 = c0; nd.child1 = c1; nd.e0 = 0; nd.e1 = 0;
+        out.g_nodes[me] = nd;
+        return (uint32_t)me;
+    }
+    void build_unified() {
+        out.g_ok = false;
+        out.g_nodes.clear(); out.g_leaves.clear(); out.g_entries.clear(); out.g_chains.clear();
+        out.g_root = 0xffffu; out.g_depth = 0;
+        out.g_chains.push_back(0); out.g_chains.push_back(0); /* id 0: no transform */
+        std::vector<GPrim> pr;
+        bool seen_medium = false;
+        out.g_first_medium = (int)out.items.size();
+        for (size_t ii = 0; ii < out.items.size(); ii++) {
+            const DItem &it = out.items[ii];
+            if (it.kind == ITEM_BVH) return;
+            if (it.kind == ITEM_MEDIUM) { if (!seen_medium) out.g_first_medium = (int)ii; seen_medium = true; continue; }
+            if (seen_medium) return; /* a solid scanned after a medium: order matters, no unified tree */
+            int chain_id = 0;
+            if (it.chain_count > 0) {
+                for (size_t k = 1; k < out.g_chains.size() / 2; k++)
+                    if (out.g_chains[2 * k] == it.chain_first && out.g_chains[2 * k + 1] == it.chain_count) chain_id = (int)k;
+                if (!chain_id) { chain_id = (int)(out.g_chains.size() / 2); out.g_chains.push_back(it.chain_first); out.g_chains.push_back(it.chain_count); }
+                if (chain_id > 127) return;
+            }
+            for (int i = it.first; i < it.first + it.count; i++) {
+                GPrim g; g.kind = it.kind; g.idx = i; g.cf = it.chain_first; g.cc = it.chain_count; g.chain_id = chain_id;
+                pr.push_back(g);
+            }
+        }
+        if (pr.size() > 0xffffffu) return;
+        /* pass 1: unpadded world boxes of the solids and of the media boundaries -> where ray origins can lie */
+        auto raw_box = [&](const GPrim &g, double pad_obj) {
+            Box b;
+            if (g.kind == ITEM_SPHERES) {
+                const DSphere &s = out.spheres[g.idx];
+                const float c0[3] = {s.cx, s.cy, s.cz}, c1[3] = {s.cx + s.vx, s.cy + s.vy, s.cz + s.vz};
+                const float r = std::fabs(s.radius);
+                for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(c0[k], c1[k]) - r; b.hi[k] = std::fmax(c0[k], c1[k]) + r; }
+            } else {
+                const DQuad &q = out.quads[g.idx];
+                for (int k = 0; k < 3; k++) {
+                    const float p0 = q.Q[k], p1 = q.Q[k] + q.u[k], p2 = q.Q[k] + q.v[k], p3 = q.Q[k] + q.u[k] + q.v[k];
+                    b.lo[k] = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3));
+                    b.hi[k] = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
+                }
+            }
+            double lo[3], hi[3];
+            for (int k = 0; k < 3; k++) { lo[k] = (double)b.lo[k] - pad_obj; hi[k] = (double)b.hi[k] + pad_obj; }
+            Box w;
+            for (int k = 0; k < 3; k++) { w.lo[k] = INFINITY; w.hi[k] = -INFINITY; }
+            for (int c = 0; c < 8; c++) {
+                double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+                chain_to_world(out.xforms, g.cf, g.cc, p);
+                for (int k = 0; k < 3; k++) {
+                    w.lo[k] = std::fmin(w.lo[k], std::nextafter((float)p[k], -INFINITY));
+                    w.hi[k] = std::fmax(w.hi[k], std::nextafter((float)p[k], INFINITY));
+                }
+            }
+            return w;
+        };
+        Box all;
+        for (int k = 0; k < 3; k++) { all.lo[k] = 0; all.hi[k] = 0; }
+        bool have_all = false;
+        auto grow = [&](const Box &w) {
+            for (int k = 0; k < 3; k++) if (!std::isfinite(w.lo[k]) || !std::isfinite(w.hi[k]) || std::fabs(w.lo[k]) > 1e15f || std::fabs(w.hi[k]) > 1e15f) return false;
+            all = have_all ? box_union(all, w) : w;
+            have_all = true;
+            return true;
+        };
+        for (const GPrim &g : pr) if (!grow(raw_box(g, 0.0))) return;
+        for (const DItem &it : out.subitems) { /* a medium scatters inside its boundary */
+            if (it.kind != ITEM_SPHERES && it.kind != ITEM_QUADS) continue;
+            for (int i = it.first; i < it.first + it.count; i++) {
+                GPrim g; g.kind = it.kind; g.idx = i; g.cf = it.chain_first; g.cc = it.chain_count; g.chain_id = 0;
+                if (!grow(raw_box(g, 0.0))) return;
+            }
+        }
+        const double diag = have_all ? box_diag(all) : 1.0;
+        double amag = 0;
+        for (int k = 0; k < 3; k++) amag = std::fmax(amag, std::fmax(std::fabs((double)all.lo[k]), std::fabs((double)all.hi[k])));
+        /* origins: the camera centre (checked per render to lie within `reach` of the box) or a point in the box */
+        const double reach = 2.0 * diag + 4.0 * amag + 10.0;
+        const double Mq = amag + reach + diag + 1.0; /* bound on every coordinate the quad test and the ray transform see */
+        const double u = 5.9604644775390625e-08;
+        /* world-space bounding sphere (centre g_c, radius g_R) of all solid sphere centres, smallest radius */
+        double cl[3] = {1e300, 1e300, 1e300}, ch[3] = {-1e300, -1e300, -1e300}, rmin = 1e300;
+        bool have_sph = false;
+        for (const GPrim &g : pr) {
+            if (g.kind != ITEM_SPHERES) continue;
+            const DSphere &s = out.spheres[g.idx];
+            for (int e = 0; e < 2; e++) {
+                double p[3] = {(double)s.cx + e * (double)s.vx, (double)s.cy + e * (double)s.vy, (double)s.cz + e * (double)s.vz};
+                chain_to_world(out.xforms, g.cf, g.cc, p);
+                for (int k = 0; k < 3; k++) { cl[k] = std::fmin(cl[k], p[k]); ch[k] = std::fmax(ch[k], p[k]); }
+            }
+            rmin = std::fmin(rmin, std::fabs((double)s.radius));
+            have_sph = true;
+        }
+        double gR = 0, mnear = 1e30, kmin = 0;
+        if (have_sph) {
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) { out.g_c[k] = (float)(0.5 * (cl[k] + ch[k])); const double h = 0.5 * (ch[k] - cl[k]); d2 += h * h; }
+            gR = std::sqrt(d2) * 1.0001 + 1e-3 * (1.0 + amag); /* + the rounding of g_c and of the device's distance */
+            mnear = 3.0 * gR + 1.0;
+            kmin = (rmin > 0) ? 20.0 * u / rmin : INFINITY;
+        }
+        out.g_R = (float)gR; out.g_mnear = (float)mnear; out.g_kmin = (float)kmin;
+        for (GPrim &g : pr) {
+            double delta = 64.0 * u * Mq + 1e-4; /* quads; the rounding of ray_at and of the ray transform */
+            if (g.kind == ITEM_SPHERES) { /* near rays: |oc| <= mnear; far rays widen their own band (g_kmin) */
+                const double r = std::fabs((double)out.spheres[g.idx].radius);
+                const double M = std::fmax(r, mnear);
+                delta += (r > 0) ? 20.0 * u * M * M / r : INFINITY;
+            }
+            g.wb = box_pad(raw_box(g, delta));
+            for (int k = 0; k < 3; k++) {
+                g.wb.lo[k] -= (float)(64.0 * u * Mq); g.wb.hi[k] += (float)(64.0 * u * Mq);
+                if (!std::isfinite(g.wb.lo[k]) || !std::isfinite(g.wb.hi[k])) return;
+            }
+        }
+        for (int k = 0; k < 3; k++) { out.g_lo[k] = all.lo[k]; out.g_hi[k] = all.hi[k]; }
+        out.g_reach = (float)reach;
+        if (!pr.empty()) {
+            std::vector<int> ids(pr.size());
+            for (size_t i = 0; i < pr.size(); i++) ids[i] = (int)i;
+            Box rb;
+            out.g_root = gen_emit(pr, ids, 0, (int)pr.size(), 0, rb);
+            if (out.status != MORT_OK) return;
+            if (out.g_nodes.size() > 0x7fff || out.g_leaves.size() > 0x7fff) return;
+        }
+        out.g_ok = true;
+    }
+
     static uint32_t tex_ref(int type, int idx) { return DREF(type & 0x7fff, idx & 0xffff); }
 
     DLambert tex_material(int tex_type, int tex_idx) {
@@ -468,6 +689,7 @@ struct Compiler {
         else { for (DItem &it : out.items) { it.accel_first = 0; if (it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) it.medium = 0; }
                for (DItem &it : out.subitems) { it.accel_first = 0; if (it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) it.medium = 0; } }
         build_own_tree();
+        build_unified();
         /* world-order copies for light sampling */
         for (int i = 0; i < o.num_spheres; i++) out.wspheres.push_back(to_dsphere(o.host_sphere[i]));
         for (int i = 0; i < o.num_quads; i++) out.wquads.push_back(to_dquad(o.host_quad[i]));

@@ -14,7 +14,7 @@ import numpy as np
 from . import structs as S
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmort_hip.so")
+LIB_PATH = os.environ.get("MORT_HIP_LIB") or os.path.join(_HERE, "lib", "libmort_hip.so")  # override: debug builds only
 _lib = None
 
 MODE_MEGA = 0
@@ -23,8 +23,9 @@ MODE_WAVE = 1
 EXPORTS = [
     "mort_hip_strerror", "mort_hip_last_error", "mort_hip_init", "mort_hip_shutdown", "mort_hip_upload_world",
     "mort_hip_set_partition", "mort_hip_rng_seed", "mort_hip_rng_load", "mort_hip_rng_store", "mort_hip_render",
-    "mort_hip_render_device", "mort_hip_local_rows", "mort_hip_global_row",
+    "mort_hip_render_device", "mort_hip_local_rows", "mort_hip_global_row", "mort_hip_rng_seed_host", "mort_hip_render_host",
 ]
+HOST_TREE = 1
 
 
 class Partition(C.Structure):
@@ -74,6 +75,10 @@ def lib():
         L.mort_hip_render_device.restype = C.c_int
         L.mort_hip_local_rows.argtypes = [ctx, C.c_int]; L.mort_hip_local_rows.restype = C.c_int
         L.mort_hip_global_row.argtypes = [ctx, C.c_int]; L.mort_hip_global_row.restype = C.c_int
+        L.mort_hip_rng_seed_host.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_void_p]; L.mort_hip_rng_seed_host.restype = C.c_int
+        L.mort_hip_render_host.argtypes = [C.POINTER(S.World), C.POINTER(S.Camera), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        L.mort_hip_render_host.restype = C.c_int
         _lib = L
     return _lib
 
@@ -146,3 +151,29 @@ class Context:
         self._chk(lib().mort_hip_render_device(self._h, C.byref(cam), mode, d_rgba, d_accum or None, stream or None,
                                                C.byref(st) if sync else None), "mort_hip_render_device")
         return st.asdict() if sync else None
+
+
+def seed_states_host(seed, width, height, dtype=None):
+    """curand_init(seed, x + y*W, 0) for every pixel, on the host (mort_hip_rng_seed_host): W*H 48-byte records."""
+    out = np.zeros(width * height * 48, dtype=np.uint8)
+    st = lib().mort_hip_rng_seed_host(seed, width, height, out.ctypes.data)
+    if st != 0:
+        raise MortHipError(st, "mort_hip_rng_seed_host")
+    return out.view(dtype) if dtype is not None else out
+
+
+def render_host(world, cam, states=None, seed=S.DEFAULT_SEED, nthreads=1, tree=False, want_accum=True, want_segments=True):
+    """`mort --mode host`: the kernel body as a host loop (mort_hip_render_host).  No GPU involved.  Returns the same
+    dict as Context.render plus the final states (raw uint8 view of the 48-byte records)."""
+    W, H = cam.image_width, cam.image_height
+    st8 = seed_states_host(seed, W, H) if states is None else np.ascontiguousarray(states).view(np.uint8).reshape(-1).copy()
+    assert st8.nbytes == W * H * 48
+    rgba = np.zeros((H, W, 4), dtype=np.uint8)
+    accum = np.zeros((H, W, 3), dtype=np.float32) if want_accum else None
+    seg = np.zeros((H, W), dtype=np.uint32) if want_segments else None
+    stt = Stats()
+    rc = lib().mort_hip_render_host(world.ptr, C.byref(cam), st8.ctypes.data, nthreads, HOST_TREE if tree else 0, rgba.ctypes.data,
+                                    accum.ctypes.data if accum is not None else None, seg.ctypes.data if seg is not None else None, C.byref(stt))
+    if rc != 0:
+        raise MortHipError(rc, "mort_hip_render_host")
+    return dict(rgba=rgba, accum=accum, segments_px=seg, stats=stt.asdict(), states=st8)

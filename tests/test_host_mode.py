@@ -1,0 +1,103 @@
+"""`mort --mode host` (mort_hip_render_host): the product's kernel body as a host loop -- the same compiled functions
+the GPU kernels run (dev_pixel.h / dev_trace.h / dev_shade.h / dev_gen.h), no GPU, no oracle in the path.  Checked here
+against the committed golden vectors and the CPU oracle, bit for bit, in both forms: the reference's scan over the
+flattened items, and the single-lane walk of this build's unified tree (what one GPU lane of mega_gen_kernel does)."""
+import os
+
+import numpy as np
+import pytest
+
+from mort_amd import host, hip, structs as S
+from tests.golden.make_golden import CASES
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = np.load(os.path.join(HERE, "golden", "oracle_golden.npz"))
+
+
+def same(out, ref, oracle):
+    assert (out["rgba"] == ref["rgba"]).all(), "uchar4 image differs"
+    assert (out["accum"].view(np.uint32) == ref["accum"].view(np.uint32)).all(), "fp32 accumulators differ (bitwise)"
+    assert (out["segments_px"] == ref["segments_px"]).all(), "per-pixel segment counts differ"
+    assert out["stats"]["segments"] == ref["segments"] and out["stats"]["rng_draws"] == ref["rng_draws"]
+    st = out["states"].view(oracle.STATE_DTYPE)
+    assert (st["d"] == ref["states"]["d"]).all() and (st["v"] == ref["states"]["v"]).all(), "final RNG states differ"
+
+
+def test_host_seeding_matches_oracle(oracle):
+    for W, H in ((200, 112), (37, 11), (5, 3)):
+        got = hip.seed_states_host(69420, W, H, oracle.STATE_DTYPE)
+        want = oracle.seed_states(69420, W, H)
+        assert (got["d"] == want["d"]).all() and (got["v"] == want["v"]).all()
+
+
+@pytest.mark.parametrize("tree", [False, True])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_host_mode_matches_oracle_and_golden(oracle, name, tree):
+    sid, width, spp, depth = CASES[name]
+    world, cam = host.build_scene(sid, width=width, spp=spp, depth=depth)
+    ref = oracle.render(world, cam, nthreads=8)
+    out = hip.render_host(world, cam, nthreads=8, tree=tree)
+    same(out, ref, oracle)
+    assert (out["rgba"] == GOLD[name + "_rgba"]).all()
+    assert (out["accum"].view(np.uint32) == GOLD[name + "_accum"].view(np.uint32)).all()
+    walked = "unified tree" in out["stats"]["kernel_name"]
+    assert walked == (tree and sid not in (1, 10))  # scenes 1 / 10 are reference BVHs: no unified tree
+
+
+def test_config1_host_serial(oracle):
+    """BASELINE config 1 as stated: Scene 1 200x112, 4 spp, host-side SERIAL loop (one thread)."""
+    world, cam = host.build_scene(1, width=200, spp=4)
+    out = hip.render_host(world, cam, nthreads=1)
+    assert (out["rgba"] == GOLD["s1_c1_rgba"]).all() and out["stats"]["eff_samples"] == 200 * 112 * 4
+    assert "1 thread" in out["stats"]["kernel_name"]
+
+
+def test_host_tree_other_views_and_thread_counts(oracle):
+    """Unified-tree walk against the oracle from inside the final scene and the Cornell box; 1 vs 5 threads agree."""
+    import ctypes as C
+    for sid, frm, at in ((9, (300.0, 250.0, 100.0), (200.0, 200.0, 400.0)), (6, (278.0, 278.0, 100.0), (200.0, 100.0, 555.0)),
+                         (7, (100.0, 300.0, 100.0), (100.0, 0.0, 100.001)), (9, (478.0, 278.0, -600.0), (0.0, 278.0, -600.0))):
+        world, cam = host.build_scene(sid, width=40, spp=4, depth=6)
+        for i in range(3):
+            cam.lookfrom.e[i] = frm[i]; cam.lookat.e[i] = at[i]
+        host.lib().mort_camera_initialize(C.byref(cam))
+        ref = oracle.render(world, cam, nthreads=8)
+        a = hip.render_host(world, cam, nthreads=1, tree=True)
+        b = hip.render_host(world, cam, nthreads=5, tree=True)
+        same(a, ref, oracle)
+        same(b, ref, oracle)
+
+
+@pytest.mark.parametrize("name", sorted(__import__("tests.worlds", fromlist=["x"]).FLAT_WORLDS))
+def test_host_tree_on_awkward_flat_worlds(oracle, name):
+    """Empty world, single primitives, coincident spheres and quads (equal t: the scan decides), concentric glass,
+    instance chains, every material lit by a sphere light (mixture + sphere_pdf), media with a quad light, and a world
+    whose list is scanned after a medium (no unified tree: order matters) -- tree walk and item scan against the oracle."""
+    from tests.worlds import FLAT_WORLDS, flat_world, flat_camera
+    spec = FLAT_WORLDS[name]
+    w, ids = flat_world(spec["prims"], media=spec.get("media", ()), late_list=spec.get("late_list", False))
+    light = ids[spec["light"][1]] if spec.get("light") else None
+    cam = flat_camera(light=light, spp=4, width=72)
+    ref = oracle.render(w, cam, nthreads=8)
+    for tree in (False, True):
+        out = hip.render_host(w, cam, nthreads=8, tree=tree)
+        same(out, ref, oracle)
+        assert ("unified tree" in out["stats"]["kernel_name"]) == (tree and name != "media_then_list")
+        if tree and name == "coincident":
+            assert out["stats"]["reference_walks"] > 0
+
+
+def test_host_tree_random_views(oracle):
+    """60 random cameras in and around the Cornell box, the smoke box and the final scene: tree walk vs oracle."""
+    import ctypes as C
+    rng = np.random.default_rng(2024)
+    for sid in (6, 7, 9):
+        world, cam = host.build_scene(sid, width=20, spp=1, depth=10)
+        for k in range(20):
+            frm, at = rng.uniform(-100, 655, 3), rng.uniform(0, 555, 3)
+            for i in range(3):
+                cam.lookfrom.e[i] = frm[i]; cam.lookat.e[i] = at[i]
+            cam.vfov = int(rng.uniform(20, 100))
+            host.lib().mort_camera_initialize(C.byref(cam))
+            ref = oracle.render(world, cam, nthreads=8)
+            same(hip.render_host(world, cam, nthreads=8, tree=True), ref, oracle)
