@@ -15,11 +15,13 @@
 
 #define GBEST_NONE 0xffffffffu
 #define GCHAIN_MEDIUM 0x7fu /* best = GENT(0, GCHAIN_MEDIUM, item index): the hit is a constant medium */
-enum { GFL_TIE = 1, GFL_REF = 2 };
+enum { GFL_REF = 2 }; /* the tree walk does not decide this ray: the scan does */
 
 /* what a walk needs besides the scene tables */
 struct GenWalk {
     const DNode2 *nodes; const uint32_t *leaves; const uint32_t *entries; const int *chains;
+    const uint32_t *ranks; /* scan-order rank of every primitive: [sphere index] then [n_spheres + quad index] (ties only) */
+    int n_spheres;
     int n_chains; uint32_t root; int first_medium;
     float gx, gy, gz, gR, mnear, kmin;
 };
@@ -75,10 +77,16 @@ DEV float gen_sphere_root(const DSphere &s, const Ray &r, float a, float t_min, 
     return root;
 }
 
+/* scan-order rank of an entry (world.cuh:122-168 visits items in order, primitives of an item in index order) */
+DEV uint32_t gen_rank(const uint32_t *ranks, int n_spheres, uint32_t e) { return ranks[(GENT_QUAD(e) ? (uint32_t)n_spheres : 0u) + GENT_IDX(e)]; }
+
 /* one primitive of a leaf: its own hit test in its own frame (sphere::hit, quad::hit :190-215, under translate::hit /
- * rotate_y::hit :268-278,334-366), t_max = closest_so_far.  Equal t (or a NaN root) is flagged: the scan decides. */
-DEV void gen_leaf_test(const DScene &sc, const int *chains, const DSphere *spheres, const DQuad *quads, uint32_t e, const Ray &ray, float ray_a,
-                       float &closest, uint32_t &best, int &flags) {
+ * rotate_y::hit :268-278,334-366), t_max = closest_so_far.  Equal t: the scan keeps whichever it meets LAST (both tests
+ * accept t == t_max), so the primitive with the higher scan rank stays -- every primitive whose own t equals the final
+ * minimum is visited (a box is pruned only if it is entered strictly later than closest_so_far), so this is the scan's
+ * choice exactly.  A NaN root is flagged: the scan itself decides that ray. */
+DEV void gen_leaf_test(const DScene &sc, const int *chains, const uint32_t *ranks, int n_spheres, const DSphere *spheres, const DQuad *quads, uint32_t e,
+                       const Ray &ray, float ray_a, float &closest, uint32_t &best, int &flags) {
     const uint32_t cid = GENT_CHAIN(e), idx = GENT_IDX(e);
     Ray r = ray;
     float ra = ray_a;
@@ -94,8 +102,10 @@ DEV void gen_leaf_test(const DScene &sc, const int *chains, const DSphere *spher
         t = gen_sphere_root(spheres[idx], r, ra, 0.001f, closest);
     }
     if (t != -1.0f) { /* accepted: t <= closest, or t is NaN */
-        if ((t == closest && best != GBEST_NONE) || !(t == t)) flags |= GFL_TIE;
-        closest = t; best = e;
+        if (!(t == t)) flags |= GFL_REF;
+        const bool tie = (t == closest) && (best != GBEST_NONE);
+        if (!tie || gen_rank(ranks, n_spheres, e) > gen_rank(ranks, n_spheres, best)) best = e;
+        closest = t;
     }
 }
 
@@ -176,7 +186,7 @@ DEV bool gen_world_hit(const DScene &sc, const GenWalk &gw, const Ray &ray, Rng 
                 const uint32_t rec = gw.leaves[cur & 0x7fffu];
                 uint32_t pos = rec & 0xffffffu;
                 for (int cnt = (int)(rec >> 24); cnt > 0; cnt--, pos++)
-                    gen_leaf_test(sc, gw.chains, sc.spheres, sc.quads, gw.entries[pos], ray, ray_a, closest, best, flags);
+                    gen_leaf_test(sc, gw.chains, gw.ranks, gw.n_spheres, sc.spheres, sc.quads, gw.entries[pos], ray, ray_a, closest, best, flags);
                 if (sp == 0) break;
                 cur = stack[--sp];
                 continue;
@@ -196,6 +206,9 @@ DEV bool gen_world_hit(const DScene &sc, const GenWalk &gw, const Ray &ray, Rng 
         }
     }
     if (flags) {
+#if defined(MORT_DEBUG_SCANS) && !defined(__HIP_DEVICE_COMPILE__)
+        printf("scan: flags %d best %08x closest %.9g o (%g %g %g) d (%g %g %g) inv (%g %g %g)\n", flags, best, closest, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, gr.ix, gr.iy, gr.iz);
+#endif
         if (scans) *scans += 1;
         gen_scan_solids(sc, gw.first_medium, gw.chains, gw.n_chains, ray, closest, best);
     }

@@ -81,9 +81,8 @@ struct __attribute__((aligned(16))) DItem { /* 32 B */
     int chain_first, chain_count;
     uint32_t mat;              /* medium: phase-function material */
     int medium;                /* medium: index into neg_inv_density[] */
-    int accel_first;           /* sphere / quad runs: node range of this build's own BVH over the run (0 count = linear scan) */
+    int pad0;
 };
-/* accel_count of a run is stored in `medium` (unused by runs) */
 
 struct __attribute__((aligned(16))) DLambert { float r, g, b; uint32_t tex; }; /* tex != 0: look up, else rgb inline */
 struct __attribute__((aligned(16))) DMetal { float r, g, b, fuzz; };

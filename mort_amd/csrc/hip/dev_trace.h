@@ -220,58 +220,6 @@ DEV void run_quads(const DScene &sc, const Ray &rw, int first, int count, int cf
     }
 }
 
-/* ---- this build's own BVH over a large run (scene_compile.h build_accels) ----
- * Equivalent to the linear scan of the run: the scan's result is (min t over the primitives whose own hit test
- * passes, ties -> the later primitive; a primitive with t equal to the incoming closest_so_far replaces the
- * earlier item's hit).  Nodes are pruned only when the ray certainly leaves the padded box before it enters it or
- * enters it beyond closest_so_far * (1 + 2e-3) + 1e-3: the slack is several times the worst-case error of the
- * fp32 root / plane evaluation (about 5e-4 relative for grazing sphere hits), so no primitive the scan would accept
- * is hidden.  Rays whose reciprocal direction is not a normal fp32 visit every node. */
-DEV bool accel_prune(const DBvhNode &nd, const SlabRay &r, float t_min, float closest) {
-    const float px0 = (nd.xmin - r.ox) * r.i32x, px1 = (nd.xmax - r.ox) * r.i32x;
-    const float py0 = (nd.ymin - r.oy) * r.i32y, py1 = (nd.ymax - r.oy) * r.i32y;
-    const float pz0 = (nd.zmin - r.oz) * r.i32z, pz1 = (nd.zmax - r.oz) * r.i32z;
-    const float t_enter = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(px0, px1), __builtin_fminf(py0, py1)),
-                                          __builtin_fmaxf(__builtin_fminf(pz0, pz1), t_min));
-    const float lim = closest * 1.002f + 1e-3f; /* closest may be +inf */
-    const float t_exit = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(px0, px1), __builtin_fmaxf(py0, py1)),
-                                         __builtin_fminf(__builtin_fmaxf(pz0, pz1), lim));
-    const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(mort_fabsf(px0), mort_fabsf(px1)), __builtin_fmaxf(mort_fabsf(py0), mort_fabsf(py1))),
-                                    __builtin_fmaxf(mort_fabsf(pz0), mort_fabsf(pz1)));
-    const float gap = t_exit - t_enter;
-    return !r.exact_only && (m < 1e30f) && (gap < -(m * 9.5367431640625e-07f));
-}
-DEV void run_accel(const DScene &sc, const Ray &r, int kind, int first, int count, int cf, int cc, float t_min, float &closest, Best &best) {
-    const SlabRay sr = slab_ray(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z);
-    const float a = vlen2(r.d);
-    const int end = first + count;
-    int node = first;
-    int best_in_run = -1;
-    while (node < end) {
-        const DBvhNode nd = sc.nodes[node];
-        const int skip = (int)(nd.skip & 0x7fffffffu);
-        if (accel_prune(nd, sr, t_min, closest)) { node = skip; continue; }
-        if (!(nd.skip >> 31)) { node = node + 1; continue; }
-        const uint32_t pa = nd.prims & 0xffffu, pb = nd.prims >> 16;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const uint32_t p = k ? pb : pa;
-            if (k == 1 && pb == pa) break;
-            const int idx = (int)(p & 0x7fffu);
-            float t, al, be;
-            bool hit;
-            if (kind == ITEM_QUADS) hit = quad_hit_t(sc.quads[idx], r, t_min, closest, t, al, be);
-            else hit = sphere_hit_t(sc.spheres[idx], r, a, t_min, closest, t);
-            /* hit: t <= closest.  Equal t: the scan keeps the later primitive, and a hit of an earlier item loses */
-            if (hit && (t < closest || best_in_run < 0 || idx > best_in_run)) {
-                closest = t; best_in_run = idx;
-                best.t = t; best.kind = (kind == ITEM_QUADS) ? HIT_QUAD : HIT_SPHERE; best.prim = idx; best.chain_first = cf; best.chain_count = cc;
-            }
-        }
-        node = skip;
-    }
-}
-
 /* ---- bvh::hit, threaded (objects.cuh:664-723) ---- */
 DEV void run_bvh(const DScene &sc, const Ray &r, int first, int count, float t_min, float &closest, Best &best) {
     const SlabRay sr = slab_ray(r.o.x, r.o.y, r.o.z, r.d.x, r.d.y, r.d.z);
@@ -329,9 +277,6 @@ DEV bool world_hit(const DScene &sc, const Ray &r, Rng &rng, Best &best) {
         const DItem it = sc.items[i];
         if (it.kind == ITEM_BVH) {
             run_bvh(sc, r, it.first, it.count, t_min, closest, best);
-        } else if ((it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) && it.medium > 0) {
-            const Ray rl = apply_chain(sc, r, it.chain_first, it.chain_count);
-            run_accel(sc, rl, it.kind, it.accel_first, it.medium, it.chain_first, it.chain_count, t_min, closest, best);
         } else if (it.kind == ITEM_SPHERES) {
             run_spheres(sc, r, it.first, it.count, it.chain_first, it.chain_count, t_min, closest, best);
         } else if (it.kind == ITEM_QUADS) {

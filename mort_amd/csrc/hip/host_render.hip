@@ -16,6 +16,7 @@
 #include <time.h>
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -34,6 +35,7 @@ struct HostJob {
     GenWalk gw;
     bool tree;
     std::atomic<int> next_row{0};
+    int row_end = 0;
     std::atomic<unsigned long long> segments{0}, draws{0}, scans{0};
 };
 
@@ -42,7 +44,7 @@ void *host_worker(void *p) {
     unsigned long long seg = 0, drw = 0, scn = 0;
     for (;;) {
         const int ly = j->next_row.fetch_add(1);
-        if (ly >= j->a.local_rows) break;
+        if (ly >= j->row_end) break;
         for (int x = 0; x < j->a.width; x++) {
             const PixelTotals t = j->tree ? render_pixel<true>(j->a, &j->gw, x, ly, &scn) : render_pixel<false>(j->a, nullptr, x, ly, nullptr);
             seg += t.segments; drw += t.draws;
@@ -106,10 +108,16 @@ extern "C" int mort_hip_render_host(const mort_world *world, const mort_camera *
     std::memset(&job.gw, 0, sizeof job.gw);
     if (job.tree) {
         job.gw.nodes = o.g_nodes.data(); job.gw.leaves = o.g_leaves.data(); job.gw.entries = o.g_entries.data(); job.gw.chains = o.g_chains.data();
+        job.gw.ranks = o.g_ranks.data(); job.gw.n_spheres = (int)o.spheres.size();
         job.gw.n_chains = (int)(o.g_chains.size() / 2); job.gw.root = o.g_root; job.gw.first_medium = o.g_first_medium;
         job.gw.gx = o.g_c[0]; job.gw.gy = o.g_c[1]; job.gw.gz = o.g_c[2]; job.gw.gR = o.g_R; job.gw.mnear = o.g_mnear; job.gw.kmin = o.g_kmin;
     }
 
+    job.row_end = H;
+    if (const char *rows = std::getenv("MORT_HOST_ROWS")) { /* debug aid: "y0,y1" renders rows [y0, y1) only */
+        int y0 = 0, y1 = H;
+        if (std::sscanf(rows, "%d,%d", &y0, &y1) == 2 && y0 >= 0 && y1 <= H && y0 < y1) { job.next_row = y0; job.row_end = y1; }
+    }
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 256) nthreads = 256;
     const double t0 = now_s();

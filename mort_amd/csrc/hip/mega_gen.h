@@ -15,6 +15,8 @@ struct GenArgs {
     uint32_t o_lambert, o_metal, o_diel, o_dlight, o_iso, o_solid, o_checker, o_image;
     uint32_t o_spheres, o_quads, o_wspheres, o_wquads, o_ltypes, o_lidxs; /* valid when prims_in_lds */
     int prims_in_lds;
+    const uint32_t *ranks; /* scan-order ranks (HBM, behind the LDS part of the image): equal-t ties only */
+    int n_spheres;
     uint32_t root;     /* child reference of the tree's root; 0xffff = no solid primitive */
     int first_medium;  /* items[first_medium .. n_items) are constant media */
     int n_chains;      /* entries of the chain table */

@@ -16,8 +16,8 @@
  *
  *  - Why the tree gives the scan's answer: header of build_unified.  The scan's result is the primitive with the
  *    smallest own t, ties -> scanned last; the walk sees every primitive whose own t is <= the final closest, keeps
- *    the minimum and FLAGS equal t; flagged rays, and rays whose reciprocal direction is not an ordinary float,
- *    repeat the segment with the scan itself (scan_solids, out of line, about never).  Constant media are evaluated
+ *    the minimum (equal t: the higher scan rank, as the scan would); rays whose reciprocal direction is not an ordinary float
+ *    repeat the segment with the scan itself (scan_solids, out of line, about never); equal t is resolved in place by scan rank.  Constant media are evaluated
  *    after the tree with the final closest_so_far, in scan order, as world::hit does (their RNG draw depends on it).
  *
  *  - Per-lane state machine, wave-level scheduling (as mega_bvh.h): T both child boxes of a node, L the primitives
@@ -130,13 +130,22 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
     float ray_a = 1, closest = 0;
     uint32_t best = GBEST_NONE; /* entry code of the closest hit so far */
     uint32_t node = 0;          /* T: tree node; L: leaf */
-    int sp = 0, flags = 0;      /* pending far children; FL_TIE / FL_REF */
+    int sp = 0, flags = 0;      /* pending far children; GFL_REF */
     V3 final_value = mk(0, 0, 0);
     StackEntry stack_deep[MORT_MAX_BOUNCE_LIMIT];
     unsigned long long ident_mask = 0ull;
     float4 *stack_lds = (float4 *)(lds + fa.off_stack);
     const int DL = fa.stack_lds_depth;
 
+#ifdef MORT_PROFILE_STATES
+    unsigned long long gp_steps[4] = {0, 0, 0, 0}, gp_lanes[4] = {0, 0, 0, 0}, gp_cyc[5] = {0, 0, 0, 0, 0}, gp_lprims = 0, gp_liters = 0;
+    unsigned long long gpt0 = __builtin_readcyclecounter(), gpt1;
+#define GPROF(i, lanes) do { gp_steps[i] += 1; gp_lanes[i] += (unsigned long long)(lanes); } while (0)
+#define GPROFC(i) do { gpt1 = __builtin_readcyclecounter(); gp_cyc[i] += gpt1 - gpt0; gpt0 = gpt1; } while (0)
+#else
+#define GPROF(i, lanes) do { } while (0)
+#define GPROFC(i) do { } while (0)
+#endif
     for (;;) {
         const unsigned long long mT = __ballot(state == G_T);
         const unsigned long long mL = __ballot(state == G_L);
@@ -150,6 +159,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
         else if (nL >= th_l) pick = G_L;
         else if (nT > 0) pick = G_T;
         else pick = (nL >= nS && nL >= nM) ? G_L : (nM >= nS ? G_M : G_S);
+        GPROFC(4);
 
         if (pick == G_T) {
             /* ---- box steps: both child boxes of one node, near child next, far child pushed ---- */
@@ -157,6 +167,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
             do {
 #pragma unroll
                 for (int rep = 0; rep < MORT_T_UNROLL; rep++) {
+                    GPROF(0, __popcll(__ballot(state == G_T)));
                     if (state == G_T) {
                         const float4 *np = (const float4 *)(nodes2 + node);
                         const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
@@ -177,15 +188,20 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                 }
                 keep = __popcll(__ballot(state == G_T));
             } while (keep >= t_keep);
+            GPROFC(0);
         } else if (pick == G_L) {
+            GPROF(1, nL);
             /* ---- leaf: the own hit test of each primitive of the leaf, in its own frame
              *      (sphere::hit objects.cuh:60-77, quad::hit :190-215 under translate / rotate_y :268-278,334-366) ---- */
             uint32_t pos = 0;
             int cnt = 0;
             if (state == G_L) { const uint32_t rec = leaves[node]; pos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
             while (__ballot(cnt > 0) != 0ull) {
+#ifdef MORT_PROFILE_STATES
+                gp_liters++; gp_lprims += (unsigned long long)__popcll(__ballot(cnt > 0));
+#endif
                 if (cnt > 0) {
-                    gen_leaf_test(lsc, chains, spheres, quads, entries[pos], ray, ray_a, closest, best, flags);
+                    gen_leaf_test(lsc, chains, ga.ranks, ga.n_spheres, spheres, quads, entries[pos], ray, ray_a, closest, best, flags);
                     pos++; cnt--;
                 }
             }
@@ -197,7 +213,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                     state = (next & 0x8000u) ? G_L : G_T;
                 } else { state = (has_media || flags) ? G_M : G_S; kind = K_SHADE; }
             }
+            GPROFC(1);
         } else if (pick == G_M) {
+            GPROF(2, nM);
             /* ---- after the solids: the scan itself for undecided rays, then the constant media in scan order
              *      (constant_medium::hit, objects.cuh:396-434; world.cuh:154-160) ---- */
             if (state == G_M) {
@@ -211,7 +229,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                 gen_media(lsc, first_medium, n_items, ray, rng, closest, best);
                 state = G_S; kind = K_SHADE;
             }
+            GPROFC(2);
         } else {
+            GPROF(3, nS);
             /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
             if (state == G_S) {
                 if (kind == K_SHADE) {
@@ -316,7 +336,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         const uint32_t root = ga.root;
                         if (ga.lane_walk & 1) { /* test knob: the whole search as one lane runs it (dev_gen.h), no scheduling */
                             GenWalk gw;
-                            gw.nodes = nodes2; gw.leaves = leaves; gw.entries = entries; gw.chains = chains; gw.n_chains = ga.n_chains;
+                            gw.nodes = nodes2; gw.leaves = leaves; gw.entries = entries; gw.chains = chains; gw.n_chains = ga.n_chains; gw.ranks = ga.ranks; gw.n_spheres = ga.n_spheres;
                             gw.root = root; gw.first_medium = first_medium;
                             gw.gx = ga.gx; gw.gy = ga.gy; gw.gz = ga.gz; gw.gR = ga.gR; gw.mnear = ga.mnear; gw.kmin = ga.kmin;
                             Best b;
@@ -340,8 +360,16 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                     }
                 }
             }
+            GPROFC(3);
         }
     }
+#ifdef MORT_PROFILE_STATES
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 4; k++) { atomicAdd(&a.counters[4 + 2 * k], gp_steps[k]); atomicAdd(&a.counters[5 + 2 * k], gp_lanes[k]); }
+        for (int k = 0; k < 5; k++) atomicAdd(&a.counters[12 + k], gp_cyc[k]);
+        atomicAdd(&a.counters[17], gp_liters); atomicAdd(&a.counters[18], gp_lprims);
+    }
+#endif
 }
 
 /* ---- host side ---- */

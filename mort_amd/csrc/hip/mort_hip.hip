@@ -135,6 +135,7 @@ struct mort_ctx {
     uint32_t gen_bytes = 0;
     GenArgs gen{};
     bool gen_ok = false;
+    int gen_prims = 0; /* solid primitives in the unified tree */
     float gen_lo[3] = {0, 0, 0}, gen_hi[3] = {0, 0, 0}, gen_reach = 0;
     int num_cus = 256;
     /* pixel-tile ordering of the BVH megakernel: most expensive tiles first (cost = segments of the previous
@@ -319,15 +320,19 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
             g.o_ltypes = (uint32_t)place(gb, o.list_types); g.o_lidxs = (uint32_t)place(gb, o.list_idxs);
         }
         gb.resize((gb.size() + 15) & ~(size_t)15, 0);
-        if (gb.size() <= 100 * 1024) {
+        const size_t lds_part = gb.size();
+        const size_t o_ranks = place(gb, o.g_ranks); /* HBM only: read when two hits have equal t */
+        if (lds_part <= 100 * 1024) {
             HIPCHK(c, hipMalloc(&c->d_gen, gb.size()));
             HIPCHK(c, hipMemcpy(c->d_gen, gb.data(), gb.size(), hipMemcpyHostToDevice));
-            c->gen_bytes = (uint32_t)gb.size();
+            c->gen_bytes = (uint32_t)lds_part;
+            g.ranks = (const uint32_t *)((const unsigned char *)c->d_gen + o_ranks); g.n_spheres = (int)o.spheres.size();
             g.root = o.g_root; g.first_medium = o.g_first_medium; g.n_chains = (int)(o.g_chains.size() / 2);
             g.gx = o.g_c[0]; g.gy = o.g_c[1]; g.gz = o.g_c[2]; g.gR = o.g_R; g.mnear = o.g_mnear; g.kmin = o.g_kmin;
             c->gen = g;
             for (int k = 0; k < 3; k++) { c->gen_lo[k] = o.g_lo[k]; c->gen_hi[k] = o.g_hi[k]; }
             c->gen_reach = o.g_reach;
+            c->gen_prims = (int)o.g_entries.size();
             c->gen_ok = true;
         }
     }
@@ -590,6 +595,13 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
      * pads were sized for (scene_compile.h build_unified) */
     bool use_gen = c->gen_ok && !use_fast && cam->sqrt_spp >= 1 && cam->sqrt_spp < 32768 && cam->bounce_limit >= 1 && W < 65536 && H < 32768 &&
                    !(force && force[0] == '1');
+    /* small worlds stay on the one-lane-per-pixel kernel: scanning a dozen primitives in lockstep keeps every lane busy,
+     * a tree walk scheduled by state does not (Cornell box 800x800x100: 53 ms vs 83 ms) */
+    if (use_gen) {
+        int min_prims = 48;
+        if (const char *mp = std::getenv("MORT_GEN_MIN_PRIMS")) min_prims = std::atoi(mp);
+        if (c->gen_prims < min_prims) use_gen = false;
+    }
     if (use_gen) {
         const float rad = std::fabs(cam->defocus_disk_u.e[0]) + std::fabs(cam->defocus_disk_u.e[1]) + std::fabs(cam->defocus_disk_u.e[2]) +
                           std::fabs(cam->defocus_disk_v.e[0]) + std::fabs(cam->defocus_disk_v.e[1]) + std::fabs(cam->defocus_disk_v.e[2]);
@@ -756,6 +768,18 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             std::fprintf(stderr, "[wf_trav sched] cycles %5.1f%%   fronts %d\n", 100.0 * (double)cnt[15] / tot, c->wf_fronts);
             std::fprintf(stderr, "[wf_trav waves] %llu waves, mean lifetime %.1f us, in-loop cycles per wave %.0f\n", cnt[21],
                          cnt[21] ? (double)cnt[20] / (double)cnt[21] * 0.01 : 0.0, cnt[21] ? tot / (double)cnt[21] : 0.0);
+        } else if (use_gen) {
+            const char *nm[4] = {"T", "L", "M", "S"};
+            unsigned long long segs = cnt[0];
+            for (int k = 0; k < 32; k++) segs += cnt[32 + 2 * k];
+            const double tot = (double)(cnt[12] + cnt[13] + cnt[14] + cnt[15] + cnt[16]);
+            for (int k = 0; k < 4; k++)
+                std::fprintf(stderr, "[gen %s] %12llu wave-steps  lanes %5.1f%%  cycles %5.1f%% (%.0f/step)\n", nm[k], cnt[4 + 2 * k],
+                             cnt[4 + 2 * k] ? 100.0 * (double)cnt[5 + 2 * k] / (64.0 * (double)cnt[4 + 2 * k]) : 0.0, 100.0 * (double)cnt[12 + k] / tot,
+                             cnt[4 + 2 * k] ? (double)cnt[12 + k] / (double)cnt[4 + 2 * k] : 0.0);
+            std::fprintf(stderr, "[gen sched] cycles %5.1f%%; leaf loop: %.2f iterations per L step, %.1f lanes per iteration; scans %llu; steps per segment: T %.2f L %.2f M %.2f S %.2f\n",
+                         100.0 * (double)cnt[16] / tot, cnt[6] ? (double)cnt[17] / (double)cnt[6] : 0.0, cnt[17] ? (double)cnt[18] / (double)cnt[17] : 0.0, cnt[3],
+                         (double)cnt[5] / (double)(segs + 1), (double)cnt[7] / (double)(segs + 1), (double)cnt[9] / (double)(segs + 1), (double)cnt[11] / (double)(segs + 1));
         } else if (use_fast) {
             const char *nm[3] = {"T", "L", "S"};
             for (int k = 0; k < 3; k++)

@@ -53,6 +53,7 @@ struct Compiled {
     std::vector<uint32_t> g_leaves;  /* first entry | count << 24 */
     std::vector<uint32_t> g_entries; /* GENT(kind, chain id, index in spheres / quads) */
     std::vector<int> g_chains;       /* chain id -> (first, count) in xforms; id 0 = no transform */
+    std::vector<uint32_t> g_ranks;   /* scan-order rank of spheres[i] at [i], of quads[i] at [n spheres + i] (equal-t ties) */
     uint32_t g_root = 0xffffu;       /* child reference of the root (0xffff: no solid primitive at all) */
     int g_first_medium = 0;          /* items[g_first_medium ..) are the constant media, tested after the tree */
     int g_depth = 0;
@@ -222,11 +223,7 @@ struct Compiler {
         out.nodes[id].prims = prims;
     }
 
-    /* ---- this build's own acceleration of large linear runs (world.cuh:122-136 and hittable_list::hit scan every
-     * primitive).  The closest hit of a run does not depend on visiting order once ties are resolved the way the
-     * scan resolves them (a later primitive replaces an equal t), so a BVH over the run gives the same answer as
-     * long as its boxes never hide a primitive the scan would accept: boxes are padded and the device prunes with
-     * a relative margin well above the evaluation error of sphere::hit / quad::hit (dev_trace.h, run_accel). ---- */
+    /* ---- boxes for this build's own trees (build_own_tree over reference BVH leaves, build_unified over everything else) ---- */
     struct Box { float lo[3], hi[3]; };
     static Box box_pad(Box b) {
         for (int k = 0; k < 3; k++) {
@@ -237,119 +234,6 @@ struct Compiler {
         }
         return b;
     }
-    Box prim_box(int kind, int idx) const {
-        Box b;
-        if (kind == ITEM_SPHERES) {
-            const DSphere &s = out.spheres[idx];
-            const float c0[3] = {s.cx, s.cy, s.cz}, c1[3] = {s.cx + s.vx, s.cy + s.vy, s.cz + s.vz};
-            for (int k = 0; k < 3; k++) {
-                b.lo[k] = std::fmin(c0[k], c1[k]) - s.radius;
-                b.hi[k] = std::fmax(c0[k], c1[k]) + s.radius;
-            }
-        } else {
-            const DQuad &q = out.quads[idx];
-            for (int k = 0; k < 3; k++) {
-                const float p0 = q.Q[k], p1 = q.Q[k] + q.u[k], p2 = q.Q[k] + q.v[k], p3 = q.Q[k] + q.u[k] + q.v[k];
-                b.lo[k] = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3));
-                b.hi[k] = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
-            }
-        }
-        return box_pad(b);
-    }
-    void accel_emit(int kind, std::vector<int> &ids, const std::vector<Box> &boxes, int lo, int hi) {
-        const size_t id = out.nodes.size();
-        Box u = boxes[ids[lo]];
-        float cmin[3], cmax[3];
-        for (int k = 0; k < 3; k++) { cmin[k] = 1e30f; cmax[k] = -1e30f; }
-        for (int i = lo; i < hi; i++) {
-            const Box &b = boxes[ids[i]];
-            for (int k = 0; k < 3; k++) {
-                u.lo[k] = std::fmin(u.lo[k], b.lo[k]); u.hi[k] = std::fmax(u.hi[k], b.hi[k]);
-                const float c = 0.5f * (b.lo[k] + b.hi[k]);
-                cmin[k] = std::fmin(cmin[k], c); cmax[k] = std::fmax(cmax[k], c);
-            }
-        }
-        DBvhNode nd;
-        std::memset(&nd, 0, sizeof nd);
-        nd.xmin = u.lo[0]; nd.xmax = u.hi[0]; nd.ymin = u.lo[1]; nd.ymax = u.hi[1]; nd.zmin = u.lo[2]; nd.zmax = u.hi[2];
-        out.nodes.push_back(nd);
-        const int n = hi - lo;
-        bool leaf = n <= 2;
-        uint32_t prims = 0;
-        if (leaf) {
-            const uint32_t kbit = (kind == ITEM_QUADS) ? 0x8000u : 0u;
-            const uint32_t pa = kbit | (uint32_t)ids[lo], pb = kbit | (uint32_t)ids[hi - 1];
-            prims = pa | (pb << 16);
-        } else {
-            /* surface-area heuristic, exhaustive sweep over the three axes (a few thousand primitives at most);
-             * the median of the widest axis when every candidate is degenerate */
-            int axis = 0;
-            if (cmax[1] - cmin[1] > cmax[axis] - cmin[axis]) axis = 1;
-            if (cmax[2] - cmin[2] > cmax[axis] - cmin[axis]) axis = 2;
-            int mid = lo + n / 2;
-            if (!std::getenv("MORT_ACCEL_MEDIAN")) {
-                double best = 1e300;
-                int bax = -1, bsplit = n / 2;
-                std::vector<int> tmp(n);
-                std::vector<double> ra(n);
-                auto area = [](const Box &b) {
-                    const double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2];
-                    return 2.0 * (x * y + y * z + z * x);
-                };
-                auto uni = [](Box a, const Box &b) { for (int k = 0; k < 3; k++) { a.lo[k] = std::fmin(a.lo[k], b.lo[k]); a.hi[k] = std::fmax(a.hi[k], b.hi[k]); } return a; };
-                for (int ax = 0; ax < 3; ax++) {
-                    std::copy(ids.begin() + lo, ids.begin() + hi, tmp.begin());
-                    std::stable_sort(tmp.begin(), tmp.end(), [&](int a, int b) { return boxes[a].lo[ax] + boxes[a].hi[ax] < boxes[b].lo[ax] + boxes[b].hi[ax]; });
-                    Box r = boxes[tmp[n - 1]]; ra[n - 1] = area(r);
-                    for (int i = n - 2; i >= 0; i--) { r = uni(r, boxes[tmp[i]]); ra[i] = area(r); }
-                    Box l = boxes[tmp[0]];
-                    for (int i = 1; i < n; i++) {
-                        /* keep the tree's depth bounded: no side smaller than an eighth */
-                        if (i >= n / 8 && n - i >= n / 8) {
-                            const double c = area(l) * i + ra[i] * (n - i);
-                            if (c < best) { best = c; bax = ax; bsplit = i; }
-                        }
-                        l = uni(l, boxes[tmp[i]]);
-                    }
-                }
-                if (bax >= 0) {
-                    std::stable_sort(ids.begin() + lo, ids.begin() + hi, [&](int a, int b) { return boxes[a].lo[bax] + boxes[a].hi[bax] < boxes[b].lo[bax] + boxes[b].hi[bax]; });
-                    mid = lo + bsplit;
-                    axis = -1;
-                }
-            }
-            if (axis >= 0)
-            std::nth_element(ids.begin() + lo, ids.begin() + mid, ids.begin() + hi, [&](int a, int b) {
-                const float ca = boxes[a].lo[axis] + boxes[a].hi[axis], cb = boxes[b].lo[axis] + boxes[b].hi[axis];
-                return ca < cb || (ca == cb && a < b);
-            });
-            accel_emit(kind, ids, boxes, lo, mid);
-            accel_emit(kind, ids, boxes, mid, hi);
-        }
-        out.nodes[id].skip = (uint32_t)out.nodes.size() | (leaf ? 0x80000000u : 0u);
-        out.nodes[id].prims = prims;
-    }
-    void build_accels(std::vector<DItem> &items) {
-        for (DItem &it : items) {
-            it.accel_first = 0;
-            if (it.kind != ITEM_SPHERES && it.kind != ITEM_QUADS) continue;
-            it.medium = 0; /* accel_count */
-            if (it.count < 16 || it.first + it.count > 0x7fff) continue;
-            std::vector<Box> boxes(it.first + it.count);
-            std::vector<int> ids;
-            bool finite = true;
-            for (int i = it.first; i < it.first + it.count; i++) {
-                boxes[i] = prim_box(it.kind, i);
-                for (int k = 0; k < 3; k++) if (!std::isfinite(boxes[i].lo[k]) || !std::isfinite(boxes[i].hi[k])) finite = false;
-                ids.push_back(i);
-            }
-            if (!finite) continue;
-            it.accel_first = (int)out.nodes.size();
-            accel_emit(it.kind, ids, boxes, 0, (int)ids.size());
-            it.medium = (int)out.nodes.size() - it.accel_first;
-        }
-    }
-
     /* ---- this build's own tree over the LEAF NODES of a reference BVH (mega_bvh.h walks it near-child-first).
      * Leaves keep the reference leaf node's box bit for bit; inner boxes are exact float unions of them, so the
      * reference's box test of a leaf implies the same test of every box above it (rounding is monotonic).  Split by
@@ -449,7 +333,8 @@ struct Compiler {
      * scan over all its solid primitives (world.cuh:122-168; instances and lists flattened into runs that share a
      * transform chain) followed by its constant media.  The scan's result is: the primitive whose OWN hit test
      * succeeds with the smallest t, equal t -> the one scanned last (each test accepts t <= closest_so_far, and a
-     * primitive's accepted root does not depend on t_max: dev_trace.h run_accel).  So any traversal that sees every
+     * primitive's accepted root does not depend on t_max: the near root if it lies in range, else the far root, and a
+     * root above t_max is never in range).  So any traversal that sees every
      * primitive whose own t is <= the final closest gives the same answer, exact ties being resolved by the scan
      * itself (the kernels fall back to it when two accepted hits have equal t).
      *
@@ -524,7 +409,7 @@ struct Compiler {
     }
     void build_unified() {
         out.g_ok = false;
-        out.g_nodes.clear(); out.g_leaves.clear(); out.g_entries.clear(); out.g_chains.clear();
+        out.g_nodes.clear(); out.g_leaves.clear(); out.g_entries.clear(); out.g_chains.clear(); out.g_ranks.clear();
         out.g_root = 0xffffu; out.g_depth = 0;
         out.g_chains.push_back(0); out.g_chains.push_back(0); /* id 0: no transform */
         std::vector<GPrim> pr;
@@ -548,6 +433,9 @@ struct Compiler {
             }
         }
         if (pr.size() > 0xffffffu) return;
+        out.g_ranks.assign(out.spheres.size() + out.quads.size(), 0u);
+        for (size_t i = 0; i < pr.size(); i++) /* pr is in scan order */
+            out.g_ranks[(pr[i].kind == ITEM_QUADS ? out.spheres.size() : 0) + (size_t)pr[i].idx] = (uint32_t)i + 1u;
         /* pass 1: unpadded world boxes of the solids and of the media boundaries -> where ray origins can lie */
         auto raw_box = [&](const GPrim &g, double pad_obj) {
             Box b;
@@ -685,9 +573,6 @@ struct Compiler {
             for (int i = 0; i < o.num_hittable_list; i++) if (!o.host_hittable_list[i].skip) flatten(MORT_OBJ_HITTABLE_LIST, i, 0, 0, 0, refs);
             emit_items(refs, out.items, true);
         }
-        if (!std::getenv("MORT_NO_ACCEL")) { build_accels(out.items); build_accels(out.subitems); }
-        else { for (DItem &it : out.items) { it.accel_first = 0; if (it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) it.medium = 0; }
-               for (DItem &it : out.subitems) { it.accel_first = 0; if (it.kind == ITEM_SPHERES || it.kind == ITEM_QUADS) it.medium = 0; } }
         build_own_tree();
         build_unified();
         /* world-order copies for light sampling */

@@ -16,6 +16,22 @@ from tests.worlds import FLAT_WORLDS, flat_world as _flat_world, flat_camera as 
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _tree_kernel_for_every_world(monkeypatch):
+    """By default worlds with fewer than 48 solid primitives stay on the one-lane-per-pixel kernel (it is faster there);
+    these tests exercise the unified-tree kernel on all of them."""
+    monkeypatch.setenv("MORT_GEN_MIN_PRIMS", "0")
+
+
+def test_default_kernel_choice(gpu_ctx, oracle, monkeypatch):
+    monkeypatch.delenv("MORT_GEN_MIN_PRIMS", raising=False)
+    for sid, want in ((6, "mega_kernel"), (9, "mega_gen_kernel"), (1, "mega_bvh_kernel")):
+        world, cam = host.build_scene(sid, width=48, spp=1)
+        out = render_gpu(gpu_ctx, world, cam, oracle=oracle)
+        assert out["stats"]["kernel_name"].startswith(want)
+        assert_same(out, oracle.render(world, cam, nthreads=8))
+
+
 @pytest.mark.parametrize("sid,width,spp,depth", [(2, 120, 4, None), (3, 120, 4, None), (4, 96, 4, None), (5, 96, 9, None),
                                                  (6, 96, 16, None), (7, 64, 9, None), (8, 72, 4, None), (9, 96, 9, None), (8, 64, 4, 6)])
 def test_unified_tree_kernel_matches_oracle(gpu_ctx, oracle, sid, width, spp, depth):
@@ -93,7 +109,7 @@ def test_small_and_awkward_flat_worlds(gpu_ctx, oracle, name):
     want = "mega_kernel" if name == "media_then_list" else "mega_gen_kernel"
     assert out["stats"]["kernel_name"].startswith(want), out["stats"]["kernel_name"]
     if name == "coincident":
-        assert out["stats"]["reference_walks"] > 0  # equal t: decided by the scan, and counted
+        assert out["stats"]["reference_walks"] == 0  # equal t is resolved in place by scan rank
 
 
 @pytest.mark.parametrize("sid,width,aspect,spp,depth", [(6, 800, None, 4, None), (8, 800, None, 1, None), (8, 1920, 16.0 / 9.0, 1, 12)])

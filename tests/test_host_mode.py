@@ -84,7 +84,7 @@ def test_host_tree_on_awkward_flat_worlds(oracle, name):
         same(out, ref, oracle)
         assert ("unified tree" in out["stats"]["kernel_name"]) == (tree and name != "media_then_list")
         if tree and name == "coincident":
-            assert out["stats"]["reference_walks"] > 0
+            assert out["stats"]["reference_walks"] == 0  # equal t is resolved in place by scan rank, not by the scan
 
 
 def test_host_tree_random_views(oracle):
@@ -101,3 +101,20 @@ def test_host_tree_random_views(oracle):
             host.lib().mort_camera_initialize(C.byref(cam))
             ref = oracle.render(world, cam, nthreads=8)
             same(hip.render_host(world, cam, nthreads=8, tree=True), ref, oracle)
+
+
+def test_grazing_hit_from_far_away_regression(monkeypatch):
+    """Final scene at 800x800, 100 spp, pixel (659, 358): one ray in 3.6e8 grazes a radius-10 cluster sphere from ~1500
+    units away, where sphere::hit's fp32 discriminant accepts a hit the exact line misses by more than round 1's fixed
+    box pads -- its per-run trees lost that hit (305 vs 429 segments for the pixel).  The unified tree sizes its pads
+    from the sphere test's error bound (scene_compile.h build_unified) and must agree with the reference's scan."""
+    monkeypatch.setenv("MORT_HOST_ROWS", "358,359")
+    world, cam = host.build_scene(8, width=800, spp=100)
+    states = hip.seed_states_host(69420, 800, 800)
+    tree = hip.render_host(world, cam, states=states, nthreads=8, tree=True)
+    scan = hip.render_host(world, cam, states=states, nthreads=8, tree=False)
+    assert "unified tree" in tree["stats"]["kernel_name"] and "item scan" in scan["stats"]["kernel_name"]
+    assert tree["segments_px"][358, 659] == scan["segments_px"][358, 659] == 305
+    assert (tree["segments_px"][358] == scan["segments_px"][358]).all()
+    assert (tree["accum"][358].view(np.uint32) == scan["accum"][358].view(np.uint32)).all()
+    assert (tree["states"] == scan["states"]).all()
