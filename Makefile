@@ -21,7 +21,7 @@ CFLAGS := -O2 -std=gnu11 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -ffp-contract=off -fno-fast-math \
             -fno-gpu-rdc -Wall -Wno-unused-parameter -Wno-unused-value -Wno-unused-result $(INC) $(HIPFLAGS_EXTRA)
 
-HOST_SRC := mort_amd/csrc/host/mort_host.c mort_amd/csrc/host/mort_scenes.c
+HOST_SRC := mort_amd/csrc/host/mort_host.c mort_amd/csrc/host/mort_scenes.c mort_amd/csrc/host/mort_jpeg.c
 HIP_SRC := $(wildcard mort_amd/csrc/hip/*.hip)
 HIP_HDR := $(wildcard mort_amd/csrc/hip/*.h) $(wildcard include/*.h)
 

@@ -49,7 +49,7 @@ typedef enum mort_status {
 
 /* render modes */
 #define MORT_MODE_MEGA 0 /* one lane per pixel, whole path on chip */
-#define MORT_MODE_WAVE 1 /* wavefront (queued) pipeline; BVH-of-spheres scenes without a light object, else MORT_ERR_UNSUPPORTED; blocking */
+#define MORT_MODE_WAVE 1 /* wavefront (queued) pipeline: every world the megakernels stage in LDS (all ten built-in scenes), else MORT_ERR_UNSUPPORTED; blocking */
 
 /* Which rows of the image this context renders: rows are grouped into blocks
  * of `rows_per_block` and this context owns blocks rank, rank+nranks, ...

@@ -105,6 +105,12 @@ int mort_scene_build(int scene_id, mort_world *w, mort_camera *cam, const mort_s
 int mort_write_ppm(const char *path, const uint8_t *rgba, int width, int height);
 /* Reads a P6 PPM into a malloc'ed tightly packed RGB buffer (caller frees). */
 unsigned char *mort_read_ppm(const char *path, int *width, int *height);
+/* Baseline JPEG -> malloc'ed tightly packed RGB (caller frees), NULL on failure: the image_texture input of scenes 3, 8, 9
+ * (img_loader.h:38-44 loads imgs/earthmap.jpg through stb_image; same integer pipeline, same bytes -- mort_jpeg.c). */
+unsigned char *mort_decode_jpeg(const unsigned char *data, size_t size, int *width, int *height);
+unsigned char *mort_read_jpeg(const char *path, int *width, int *height);
+/* By extension: .jpg / .jpeg through mort_read_jpeg, anything else through mort_read_ppm. */
+unsigned char *mort_read_image(const char *path, int *width, int *height);
 
 #ifdef __cplusplus
 }

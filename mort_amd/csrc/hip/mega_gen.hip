@@ -34,7 +34,7 @@
 
 #include "mega_gen.h"
 #include "dev_gen.h"
-#include "dev_shade.h"
+#include "dev_shade_call.h"
 
 #pragma clang fp contract(off)
 
@@ -52,25 +52,6 @@ __device__ __attribute__((noinline)) ScanHit scan_solids(const DScene *scp, int 
     ScanHit h;
     gen_scan_solids(*scp, first_medium, chains, n_chains, r, h.closest, h.best);
     return h;
-}
-
-/* Shading is out of line: one call per segment with everything passed in registers.  (Inlined into the state loop, hipcc 7.2
- * -O3 produced a kernel whose scattered-ray origin was wrong for a few rays per thousand -- correct at -O1, correct with
- * a printf next to it, correct out of line; the parity tests against the oracle are what guards this.)  It also keeps the
- * shade step's registers out of the traversal steps. */
-struct ShadeRet { float ox, oy, oz, dx, dy, dz, tm, kx, ky, kz, rp, fx, fy, fz; int flags; uint32_t d, v0, v1, v2, v3, v4, draws; };
-__device__ __attribute__((noinline)) ShadeRet shade_call(const DScene *scp, int light_type, int light_idx, float ox, float oy, float oz, float dx, float dy, float dz, float tm,
-                                                         float time0, float t, int kind, int prim, int cf, int cc, uint32_t d, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t draws) {
-    Ray ray; ray.o = mk(ox, oy, oz); ray.d = mk(dx, dy, dz); ray.tm = tm;
-    Best b; b.t = t; b.kind = kind; b.prim = prim; b.chain_first = cf; b.chain_count = cc;
-    Rng rng; rng.d = d; rng.v0 = v0; rng.v1 = v1; rng.v2 = v2; rng.v3 = v3; rng.v4 = v4; rng.draws = draws;
-    const ShadeOut so = shade_hit(*scp, light_type, light_idx, ray, time0, b, rng);
-    ShadeRet r;
-    r.ox = ray.o.x; r.oy = ray.o.y; r.oz = ray.o.z; r.dx = ray.d.x; r.dy = ray.d.y; r.dz = ray.d.z; r.tm = ray.tm;
-    r.kx = so.e.kx; r.ky = so.e.ky; r.kz = so.e.kz; r.rp = so.e.rp; r.fx = so.final_value.x; r.fy = so.final_value.y; r.fz = so.final_value.z;
-    r.flags = (so.done ? 1 : 0) | (so.ident ? 2 : 0);
-    r.d = rng.d; r.v0 = rng.v0; r.v1 = rng.v1; r.v2 = rng.v2; r.v3 = rng.v3; r.v4 = rng.v4; r.draws = rng.draws;
-    return r;
 }
 
 template <int BLOCK, bool PRIMS_LDS>
@@ -255,15 +236,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         if (lofs == a.debug_lofs) printf("   decode: kind %d prim %d chain %d+%d t %.9g | chains[0..3] %d %d %d %d o_chains %u\n", b.kind, b.prim, b.chain_first, b.chain_count, b.t,
                             chains[0], chains[1], chains[2], chains[3], ga.o_chains);
 #endif
-                        ShadeOut so;
-                        {
-                            const ShadeRet r = shade_call(&s_lsc, a.light_type, a.light_idx, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tm, ray_time0,
-                                                          b.t, b.kind, b.prim, b.chain_first, b.chain_count, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4, rng.draws);
-                            ray.o = mk(r.ox, r.oy, r.oz); ray.d = mk(r.dx, r.dy, r.dz); ray.tm = r.tm;
-                            so.e.kx = r.kx; so.e.ky = r.ky; so.e.kz = r.kz; so.e.rp = r.rp; so.final_value = mk(r.fx, r.fy, r.fz);
-                            so.done = r.flags & 1; so.ident = (r.flags & 2) != 0;
-                            rng.d = r.d; rng.v0 = r.v0; rng.v1 = r.v1; rng.v2 = r.v2; rng.v3 = r.v3; rng.v4 = r.v4; rng.draws = r.draws;
-                        }
+                        const ShadeOut so = shade_hit_outlined(&s_lsc, a.light_type, a.light_idx, ray, ray_time0, b, rng);
 #ifdef MORT_DEBUG_PRINT
                         if (lofs == a.debug_lofs) printf("   shaded: done %d ident %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", (int)so.done, (int)so.ident, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
 #endif

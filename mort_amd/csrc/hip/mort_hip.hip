@@ -30,6 +30,7 @@
 #include "seed_host.h"
 #include "mort_internal.h"
 #include "mega_gen.h"
+#include "wave_gen.h"
 
 #pragma clang fp contract(off)
 
@@ -613,13 +614,40 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
     int lds_bytes_used = 0, gen_block_used = 0;
     const void *fast_kernel_used = nullptr;
     char kname[64] = "mega_kernel";
+    /* the wavefront pipeline: wave_bvh.h for one reference BVH of spheres as the world (no light object), wave_gen.hip for
+     * every world with a unified tree (lights, quads, instances, media); anything else is not supported in this mode */
+    const bool wave_bvh = c->wave_ok && c->fast_ok && cam->light_obj_type == -1;
+    bool wave_gen = false;
     if (mode == MORT_MODE_WAVE) {
-        /* the wavefront pipeline covers: one BVH of spheres as the world, no light object */
-        if (!(c->wave_ok && c->fast_ok && cam->light_obj_type == -1 && cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1))
-            return MORT_ERR_UNSUPPORTED;
+        if (!(cam->sqrt_spp >= 1 && cam->sqrt_spp < 4096 && cam->bounce_limit >= 1)) return MORT_ERR_UNSUPPORTED;
+        if (!wave_bvh) {
+            wave_gen = c->gen_ok;
+            const float rad = std::fabs(cam->defocus_disk_u.e[0]) + std::fabs(cam->defocus_disk_u.e[1]) + std::fabs(cam->defocus_disk_u.e[2]) +
+                              std::fabs(cam->defocus_disk_v.e[0]) + std::fabs(cam->defocus_disk_v.e[1]) + std::fabs(cam->defocus_disk_v.e[2]);
+            for (int k = 0; k < 3 && wave_gen; k++) {
+                const float v = cam->center.e[k];
+                if (!(v - rad >= c->gen_lo[k] - c->gen_reach && v + rad <= c->gen_hi[k] + c->gen_reach)) wave_gen = false;
+            }
+            if (!wave_gen) return MORT_ERR_UNSUPPORTED;
+        }
     }
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
-    if (blocks > 0 && mode == MORT_MODE_WAVE) {
+    if (blocks > 0 && mode == MORT_MODE_WAVE && wave_gen) {
+        GenArgs ga = c->gen;
+        ga.f.r = a;
+        ga.f.hot_src = (const unsigned char *)c->d_gen; ga.f.hot_bytes = c->gen_bytes;
+        if (!c->h_live) HIPCHK(c, hipHostMalloc((void **)&c->h_live, 64));
+        WfGenHost hb;
+        hb.d_wf = &c->d_wf; hb.wf_bytes = &c->wf_bytes; hb.h_live = &c->h_live; hb.fronts = &c->wf_fronts; hb.num_cus = c->num_cus;
+        unsigned live_left = 0;
+        hipError_t e_w = mort_wave_gen_render(ga, hb, cam->bounce_limit, cam->sqrt_spp, s, &live_left);
+        if (e_w != hipSuccess) {
+            if (live_left) { c->last_error = "wavefront: front limit reached with live pixels"; return MORT_ERR_HIP; }
+            return hip_fail(c, e_w, "mort_wave_gen_render");
+        }
+        lds_bytes_used = (int)c->gen_bytes;
+        std::snprintf(kname, sizeof kname, "wf_trav_gen<%s>", ga.prims_in_lds ? "true" : "false");
+    } else if (blocks > 0 && mode == MORT_MODE_WAVE) {
         int st_w = render_wavefront(c, a, cam, s);
         if (st_w != MORT_OK) return st_w;
         lds_bytes_used = (int)c->fast_bytes;
@@ -815,7 +843,8 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         stats->local_rows = a.local_rows;
         std::memcpy(stats->kernel_name, kname, sizeof stats->kernel_name);
         hipFuncAttributes fattr;
-        const void *kf = mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
+        const void *kf = (mode == MORT_MODE_WAVE && wave_gen) ? mort_wave_gen_trav_kernel(c->gen.prims_in_lds != 0, nullptr)
+                         : mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
                          : fast_kernel_used;
         const bool gen_ran = use_gen && mode != MORT_MODE_WAVE && gen_block_used > 0;
         if ((gen_ran ? mort_gen_attributes(gen_block_used, c->gen.prims_in_lds != 0, &fattr) : hipFuncGetAttributes(&fattr, kf)) == hipSuccess) {

@@ -37,23 +37,7 @@
 #define MORT_WAVE_BVH_H
 
 #include "mega_bvh.h" /* own-tree walk: own_prune, slab_check, reference_walk */
-
-struct __attribute__((aligned(16))) WfRay { float ox, oy, oz, tm; float dx, dy, dz, time0; };
-struct __attribute__((aligned(8))) WfHit { float t; int best; };
-struct __attribute__((aligned(16))) WfPix {
-    uint32_t d, v0, v1, v2;
-    uint32_t v3, v4; float cr, cg;
-    float cb; uint32_t packed; /* s_i | s_j << 12 | iter << 24 */ uint32_t segments, draws;
-};
-
-enum { WC_LAMB = 0, WC_SPEC = 1, WC_FIN = 2 };
-
-struct WfCounters {
-    unsigned front_count[2];  /* records in front[parity] */
-    unsigned cls_count[2][3]; /* positions in the class queues of front parity */
-    unsigned live;            /* pixels not finished yet */
-    unsigned pad[7];
-};
+#include "wave_common.h"
 
 struct WfArgs {
     RenderArgs r;
@@ -72,9 +56,6 @@ struct WfArgs {
     WfCounters *cnt;
     int parity;               /* front & 1 */
 };
-
-DEV Rng wf_rng_load(const WfPix &p) { Rng r; r.d = p.d; r.v0 = p.v0; r.v1 = p.v1; r.v2 = p.v2; r.v3 = p.v3; r.v4 = p.v4; r.draws = p.draws; return r; }
-DEV void wf_rng_store(WfPix &p, const Rng &r) { p.d = r.d; p.v0 = r.v0; p.v1 = r.v1; p.v2 = r.v2; p.v3 = r.v3; p.v4 = r.v4; p.draws = r.draws; }
 
 /* ---- front 0: load streams, first camera ray of every pixel ---- */
 extern "C" __global__ void __launch_bounds__(256) wf_init(const WfArgs w) {

@@ -114,9 +114,31 @@ def synthetic_earth(width=1024, height=512):
 _EARTH_FIXTURE = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap_rgb.npz")
 
 
+_EARTH_JPEG = os.path.join(os.path.dirname(_HERE), "tests", "golden", "earthmap.jpg")
+
+
+def read_image(path):
+    """JPEG (the product's own baseline decoder, mort_jpeg.c) or PPM -> HxWx3 uint8, or None."""
+    L = lib()
+    L.mort_read_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mort_read_image.restype = C.c_void_p
+    w, h = C.c_int(0), C.c_int(0)
+    p = L.mort_read_image(path.encode(), C.byref(w), C.byref(h))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(h.value, w.value, 3)).copy()
+    C.CDLL(None).free(C.c_void_p(p))
+    return out
+
+
 def load_earth():
-    """Texels of the reference's imgs/earthmap.jpg as decoded by its vendored stb_image.h
-    (fixture made by oracle/_ref/stb_decode, tests/golden/make_golden.py); synthetic stand-in if absent."""
+    """Texels of the reference's imgs/earthmap.jpg (tests/golden/earthmap.jpg is that data file), decoded by the
+    product's own JPEG decoder -- byte-identical to the reference's stb_image decode (tests/test_jpeg.py pins it against
+    tests/golden/earthmap_rgb.npz); the decoded fixture or a synthetic stand-in if the file is absent."""
+    if os.path.exists(_EARTH_JPEG):
+        img = read_image(_EARTH_JPEG)
+        if img is not None:
+            return img
     if os.path.exists(_EARTH_FIXTURE):
         return np.ascontiguousarray(np.load(_EARTH_FIXTURE)["rgb"])
     return synthetic_earth()

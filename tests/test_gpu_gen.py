@@ -153,3 +153,63 @@ def test_full_size_frames_agree_between_kernels(oracle, monkeypatch, sid, width,
         assert (a["seg"] == other["seg"]).all() and a["total"] == other["total"] == int(a["seg"].sum())
         assert (a["states"]["d"] == other["states"]["d"]).all() and (a["states"]["v"] == other["states"]["v"]).all()
     assert (a["rgba"][..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("sid,width,spp,depth", [(2, 96, 4, None), (3, 96, 4, None), (4, 64, 4, None), (5, 64, 9, None), (6, 96, 16, None),
+                                                 (7, 64, 9, None), (8, 72, 4, None), (9, 96, 9, None), (8, 64, 4, 6), (6, 61, 5, 3)])
+def test_wavefront_mode_on_unified_tree_worlds(gpu_ctx, oracle, sid, width, spp, depth):
+    """MORT_MODE_WAVE (wave_gen.hip) on every non-BVH scene -- BASELINE config 5 is scene 8 through this mode -- gives the
+    oracle's bits: lights / MIS, quads, instance chains, media (their stream draws happen in the shade kernel)."""
+    world, cam = host.build_scene(sid, width=width, spp=spp, depth=depth)
+    ref = oracle.render(world, cam, nthreads=16)
+    gpu_ctx.set_partition(0, 1, 8)
+    gpu_ctx.upload_world(world)
+    gpu_ctx.rng_seed(S.DEFAULT_SEED, cam.image_width, cam.image_height)
+    out = gpu_ctx.render(cam, mode=hip.MODE_WAVE, want_accum=True, want_segments=True)
+    out["states"] = gpu_ctx.rng_store(cam.image_width, cam.image_height, oracle.STATE_DTYPE)
+    assert out["stats"]["kernel_name"].startswith("wf_trav_gen")
+    assert_same(out, ref)
+
+
+@pytest.mark.parametrize("name", ["coincident", "boxes_and_instances", "every_material_lit_by_sphere", "lit_by_quad_with_media", "empty"])
+def test_wavefront_mode_on_awkward_flat_worlds(gpu_ctx, oracle, name):
+    spec = FLAT_WORLDS[name]
+    w, ids = _flat_world(spec["prims"], media=spec.get("media", ()))
+    cam = _flat_camera(light=ids[spec["light"][1]] if spec.get("light") else None, spp=4, width=96)
+    ref = oracle.render(w, cam, nthreads=16)
+    gpu_ctx.set_partition(0, 1, 8)
+    gpu_ctx.upload_world(w)
+    gpu_ctx.rng_seed(S.DEFAULT_SEED, cam.image_width, cam.image_height)
+    out = gpu_ctx.render(cam, mode=hip.MODE_WAVE, want_accum=True, want_segments=True)
+    out["states"] = gpu_ctx.rng_store(cam.image_width, cam.image_height, oracle.STATE_DTYPE)
+    assert_same(out, ref)
+
+
+def test_wavefront_and_megakernel_agree_at_config_size(oracle):
+    """Final scene at 800x800 (config 5's scene; its 4096x4096 x 10000 spp is an 8-GPU job), 1 spp: the wavefront form and
+    the unified-tree megakernel agree on every byte, accumulator bit, segment count and final stream word; a two-way row
+    partition of the wavefront render composes to the same frame."""
+    world, cam = host.build_scene(8, width=800, spp=1)
+    W, H = cam.image_width, cam.image_height
+    outs = []
+    for mode, nranks in ((hip.MODE_MEGA, 1), (hip.MODE_WAVE, 1), (hip.MODE_WAVE, 2)):
+        rgba = np.zeros((H, W, 4), np.uint8); acc = np.zeros((H, W, 3), np.float32); seg = np.zeros((H, W), np.uint32)
+        total = 0
+        states = None
+        with hip.Context(0) as ctx:
+            for r in range(nranks):
+                ctx.set_partition(r, nranks, 8)
+                ctx.upload_world(world)
+                ctx.rng_seed(S.DEFAULT_SEED, W, H)
+                o = ctx.render(cam, mode=mode, want_accum=True, want_segments=True)
+                rows = [ctx.global_row(l) for l in range(ctx.local_rows(H))]
+                rgba[rows] = o["rgba"][rows]; acc[rows] = o["accum"][rows]; seg[rows] = o["segments_px"][rows]
+                total += o["stats"]["segments"]
+                st = ctx.rng_store(W, H, oracle.STATE_DTYPE).reshape(H, W)
+                states = st.copy() if states is None else states
+                states[rows] = st[rows]
+        outs.append((rgba, acc, seg, total, states))
+    a = outs[0]
+    for b in outs[1:]:
+        assert (a[0] == b[0]).all() and (a[1].view(np.uint32) == b[1].view(np.uint32)).all() and (a[2] == b[2]).all() and a[3] == b[3]
+        assert (a[4]["d"] == b[4]["d"]).all() and (a[4]["v"] == b[4]["v"]).all()

@@ -181,10 +181,14 @@ def test_wavefront_mode_matches_oracle(gpu_ctx, oracle, sid, width, spp, depth):
     assert_same(out, ref)
 
 
-def test_wavefront_mode_rejects_unsupported_scenes(gpu_ctx):
-    world, cam = host.build_scene(6, width=32, spp=1)  # lights + quads: megakernel only for now
+def test_wavefront_mode_rejects_unsupported_worlds(gpu_ctx):
+    """A world whose list is scanned after a medium has no unified tree (order matters): megakernel only."""
+    from tests.worlds import FLAT_WORLDS, flat_world, flat_camera
+    spec = FLAT_WORLDS["media_then_list"]
+    w, _ = flat_world(spec["prims"], media=spec["media"], late_list=True)
+    cam = flat_camera(spp=1, width=32)
     gpu_ctx.set_partition(0, 1, 8)
-    gpu_ctx.upload_world(world)
+    gpu_ctx.upload_world(w)
     gpu_ctx.rng_seed(1, cam.image_width, cam.image_height)
     with pytest.raises(hip.MortHipError) as e:
         gpu_ctx.render(cam, mode=hip.MODE_WAVE)

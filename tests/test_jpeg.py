@@ -1,0 +1,43 @@
+"""The product's own baseline JPEG decoder (mort_amd/csrc/host/mort_jpeg.c) against the reference's decode of its one
+image asset: tests/golden/earthmap.jpg is imgs/earthmap.jpg (a data file of the reference), tests/golden/earthmap_rgb.npz
+the bytes its vendored stb_image produces from it (oracle/_ref/stb_decode, tests/golden/make_golden.py).  JPEG decoding
+is integer arithmetic: the match must be exact."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from mort_amd import host
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _decode(path):
+    L = host.lib()
+    L.mort_read_image.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mort_read_image.restype = C.c_void_p
+    w, h = C.c_int(0), C.c_int(0)
+    p = L.mort_read_image(path.encode(), C.byref(w), C.byref(h))
+    if not p:
+        return None
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(h.value, w.value, 3)).copy()
+    C.CDLL(None).free(C.c_void_p(p))
+    return out
+
+
+def test_earthmap_decodes_to_the_reference_texels():
+    got = _decode(os.path.join(HERE, "golden", "earthmap.jpg"))
+    want = np.load(os.path.join(HERE, "golden", "earthmap_rgb.npz"))["rgb"]
+    assert got is not None and got.shape == want.shape == (512, 1024, 3)
+    assert (got == want).all(), f"{int((got != want).sum())} bytes differ"
+
+
+def test_rejects_what_it_does_not_decode(tmp_path):
+    data = open(os.path.join(HERE, "golden", "earthmap.jpg"), "rb").read()
+    bad = tmp_path / "prog.jpg"
+    bad.write_bytes(data.replace(bytes([0xff, 0xc0]), bytes([0xff, 0xc2]), 1))  # SOF0 -> SOF2 (progressive)
+    assert _decode(str(bad)) is None
+    trunc = tmp_path / "trunc.jpg"
+    trunc.write_bytes(data[:200])
+    assert _decode(str(trunc)) is None
+    assert _decode(str(tmp_path / "missing.jpg")) is None
