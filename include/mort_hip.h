@@ -72,6 +72,7 @@ typedef struct mort_stats {
     int kernel_vgprs, kernel_lds_bytes; /* launch facts, for reports */
     uint64_t reference_walks; /* BVH megakernel: segments re-traced with the reference's own walk */
     char kernel_name[64];    /* dominant kernel of this render as rocprofv3 names it (template arguments included) */
+    double gather_seconds;   /* mort_hip_render_gather: device time of the frame gather (RCCL + de-interleave + copy out) */
 } mort_stats;
 
 const char *mort_hip_strerror(int status);
@@ -120,6 +121,20 @@ int mort_hip_render_device(mort_ctx *ctx, const mort_camera *cam, int mode, void
 int mort_hip_rng_seed_host(uint64_t seed, int width, int height, mort_rng_state *states);
 int mort_hip_render_host(const mort_world *world, const mort_camera *cam, mort_rng_state *states, int nthreads, int flags,
                          uint8_t *rgba_out, float *accum_out, uint32_t *segments_px_out, mort_stats *stats);
+
+/* ---- multi-GPU: one process (one context) per GPU, image rows partitioned with mort_hip_set_partition, ONE exchange step:
+ * the packed uchar4 rows of every rank are gathered to rank 0 over RCCL and de-interleaved there (the reference is
+ * single-GPU).  Rank 0 obtains an id (mort_hip_comm_id) and hands its MORT_COMM_ID_BYTES bytes to the other ranks by any
+ * means (the CLI uses pipes to the ranks it forked); every rank then calls mort_hip_comm_init (collective) after
+ * mort_hip_set_partition(rank, nranks, rows_per_block).  mort_hip_render_gather = render + gather, collective, blocking;
+ * rank 0 receives the full W*H*4 frame in rgba_out (other ranks may pass NULL).  With nranks == 1 no communicator is needed. */
+#define MORT_COMM_ID_BYTES 128
+int mort_hip_comm_id(void *id);
+int mort_hip_comm_init(mort_ctx *ctx, const void *id, int rank, int nranks);
+void mort_hip_comm_destroy(mort_ctx *ctx);
+int mort_hip_render_gather(mort_ctx *ctx, const mort_camera *cam, int mode, uint8_t *rgba_out, mort_stats *stats);
+/* One-rank rehearsal of the RCCL path (library load, communicator, grouped send / recv to self, de-interleave): MORT_OK when the bytes come back. */
+int mort_hip_comm_selftest(mort_ctx *ctx);
 
 /* Number of rows owned for an image of `height` rows under the current partition. */
 int mort_hip_local_rows(const mort_ctx *ctx, int height);

@@ -1,16 +1,27 @@
 /*
- * mort -- command line of the renderer: `mort <scene_id>` as in the reference
- * (mort.cu:633-689), plus overrides and file output (the reference only draws
- * into a GLUT window).  Host code is C; the render goes through the C ABI of
- * libmort_hip.so.  Errors print and exit like HANDLE_ERROR (include/book.h:21-30).
+ * mort -- command line of the renderer: `mort <scene_id>` as in the reference (mort.cu:633-689), plus overrides, file
+ * output (the reference only draws into a GLUT window) and the multi-GPU / host modes the north_star names.  Host code
+ * is C; every render goes through the C ABI of libmort_hip.so.  Errors print and exit like HANDLE_ERROR
+ * (include/book.h:21-30).
  *
- *   mort <scene_id> [--width W] [--aspect A] [--spp N] [--depth D] [--seed S]
- *                   [--out file.ppm] [--dump-f32 file.raw] [--states-in f] [--states-out f]
- *                   [--earth file.ppm] [--rtl] [--frames N] [--device K] [--mode mega|wave]
+ *   mort <scene_id> [--width W] [--aspect A] [--spp N] [--depth D] [--seed S] [--frames N]
+ *                   [--mode mega|wave|host] [--threads T] [--tree]       host: the kernel body as a host loop (no GPU)
+ *                   [--gpus N] [--devices a,b,..] [--gather rccl|shm]     one process per GPU, rows partitioned, one gather
+ *                   [--out f.ppm] [--dump-f32 f.raw] [--states-in f] [--states-out f] [--earth img] [--rtl] [--device K]
+ *
+ * --gpus N: N - 1 ranks are forked BEFORE any HIP call (a process that has initialised the GPU must not fork or exec);
+ * rank r renders row blocks r, r + N, ... on device r (or --devices) and the packed rows are gathered to rank 0 -- over
+ * RCCL (`--gather rccl`, the default: xGMI inside a node), or through a shared host mapping (`--gather shm`: for ranks
+ * that share one GPU, where RCCL refuses a communicator; used by the tests on a one-GPU box).
  */
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "mort_hip.h"
 #include "mort_host.h"
@@ -19,18 +30,43 @@ static void die(mort_ctx *ctx, int st, const char *what) {
     fprintf(stderr, "%s: %s %s\n", what, mort_hip_strerror(st), ctx ? mort_hip_last_error(ctx) : "");
     exit(EXIT_FAILURE);
 }
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
+
+static int usage(void) {
+    printf("Usage: mort <number_between_1_and_10> [--width W] [--aspect A] [--spp N] [--depth D] [--seed S] [--frames N] "
+           "[--mode mega|wave|host] [--threads T] [--tree] [--gpus N] [--devices a,b,..] [--gather rccl|shm] "
+           "[--out f.ppm] [--dump-f32 f.raw] [--states-in f] [--states-out f] [--earth image.jpg|.ppm] [--rtl] [--device K]\n");
+    return -1;
+}
+
+/* the reference loads "imgs/earthmap.jpg" relative to the working directory (mort.cu:296,599) */
+static unsigned char *load_earth(const char *path, const char *argv0, int *w, int *h, char *used, size_t used_len) {
+    if (path) { snprintf(used, used_len, "%s", path); return mort_read_image(path, w, h); }
+    const char *cands[3] = {"imgs/earthmap.jpg", "tests/golden/earthmap.jpg", NULL};
+    char rel[4096];
+    for (int i = 0; i < 3; i++) {
+        const char *p = cands[i];
+        if (!p) { /* next to the binary: <repo>/mort_amd/bin/mort -> <repo>/tests/golden/earthmap.jpg */
+            const char *slash = strrchr(argv0, '/');
+            if (!slash) break;
+            snprintf(rel, sizeof rel, "%.*s/../../tests/golden/earthmap.jpg", (int)(slash - argv0), argv0);
+            p = rel;
+        }
+        unsigned char *t = mort_read_image(p, w, h);
+        if (t) { snprintf(used, used_len, "%s", p); return t; }
+    }
+    snprintf(used, used_len, "imgs/earthmap.jpg");
+    return NULL;
+}
 
 int main(int argc, char **argv) {
-    if (argc < 2) {
-        printf("Usage: mort <number_between_1_and_10> [--width W] [--aspect A] [--spp N] [--depth D] [--seed S] "
-               "[--out f.ppm] [--dump-f32 f.raw] [--states-in f] [--states-out f] [--earth f.ppm] [--rtl] [--frames N]\n");
-        return -1;
-    }
+    if (argc < 2) return usage();
     int scene = atoi(argv[1]);
-    int width = 0, spp = 0, depth = -1, frames = 1, device = 0, rtl = 0, mode = MORT_MODE_MEGA;
+    int width = 0, spp = 0, depth = -1, frames = 1, device = 0, rtl = 0, mode = MORT_MODE_MEGA, host_mode = 0, threads = 1, tree = 0;
+    int gpus = 1, gather_shm = 0, devices[64], n_devices = 0;
     double aspect = 0;
     unsigned long long seed = MORT_DEFAULT_SEED;
-    const char *out = NULL, *dump = NULL, *sin = NULL, *sout = NULL, *earth = "tests/golden/earthmap.ppm";
+    const char *out = NULL, *dump = NULL, *sin = NULL, *sout = NULL, *earth = NULL;
     for (int i = 2; i < argc; i++) {
 #define ARG(name) (strcmp(argv[i], name) == 0 && i + 1 < argc)
         if (ARG("--width")) width = atoi(argv[++i]);
@@ -45,10 +81,27 @@ int main(int argc, char **argv) {
         else if (ARG("--earth")) earth = argv[++i];
         else if (ARG("--frames")) frames = atoi(argv[++i]);
         else if (ARG("--device")) device = atoi(argv[++i]);
-        else if (ARG("--mode")) { const char *m = argv[++i]; mode = (strcmp(m, "wave") == 0) ? MORT_MODE_WAVE : MORT_MODE_MEGA; }
+        else if (ARG("--threads")) threads = atoi(argv[++i]);
+        else if (ARG("--gpus")) gpus = atoi(argv[++i]);
+        else if (ARG("--devices")) {
+            char *s = argv[++i];
+            for (char *tok = strtok(s, ","); tok && n_devices < 64; tok = strtok(NULL, ",")) devices[n_devices++] = atoi(tok);
+        }
+        else if (ARG("--gather")) { const char *g = argv[++i]; if (strcmp(g, "shm") == 0) gather_shm = 1; else if (strcmp(g, "rccl") != 0) { fprintf(stderr, "unknown gather %s\n", g); return -1; } }
+        else if (ARG("--mode")) {
+            const char *m = argv[++i];
+            if (strcmp(m, "wave") == 0) mode = MORT_MODE_WAVE;
+            else if (strcmp(m, "host") == 0) host_mode = 1;
+            else if (strcmp(m, "mega") != 0) { fprintf(stderr, "unknown mode %s\n", m); return -1; }
+        }
         else if (strcmp(argv[i], "--rtl") == 0) rtl = 1;
-        else { fprintf(stderr, "unknown option %s\n", argv[i]); return -1; }
+        else if (strcmp(argv[i], "--tree") == 0) tree = 1;
+        else { fprintf(stderr, "unknown option %s\n", argv[i]); return usage(); }
     }
+    if (gpus < 1 || gpus > 64 || frames < 1 || threads < 1) { fprintf(stderr, "bad --gpus / --frames / --threads\n"); return -1; }
+    if (host_mode && gpus != 1) { fprintf(stderr, "--mode host runs on the host: --gpus does not apply\n"); return -1; }
+    if (gpus > 1 && (dump || sin || sout)) { fprintf(stderr, "--dump-f32 / --states-in / --states-out are single-GPU options\n"); return -1; }
+    if (n_devices && n_devices != gpus) { fprintf(stderr, "--devices needs %d entries\n", gpus); return -1; }
 
     mort_world world;
     mort_camera cam;
@@ -58,8 +111,12 @@ int main(int argc, char **argv) {
     opts.args_rtl = rtl;
     unsigned char *texels = NULL;
     if (scene == 3 || scene == 8 || scene == 9) {
-        texels = mort_read_ppm(earth, &opts.earth_width, &opts.earth_height);
-        if (!texels) fprintf(stderr, "ERROR: Could not load image file '%s'.\n", earth); /* img_loader.h:33 */
+        char used[4096];
+        texels = load_earth(earth, argv[0], &opts.earth_width, &opts.earth_height, used, sizeof used);
+        if (!texels) { /* img_loader.h:33 prints this and renders the missing-texture colour; a batch render of the wrong picture helps nobody */
+            fprintf(stderr, "ERROR: Could not load image file '%s'.\n", used);
+            return EXIT_FAILURE;
+        }
         opts.earth_texels = texels;
     }
     mort_scene_build(scene, &world, &cam, &opts);
@@ -69,39 +126,120 @@ int main(int argc, char **argv) {
     if (depth >= 0) cam.bounce_limit = depth;
     mort_camera_initialize(&cam);
     const int W = cam.image_width, H = cam.image_height;
+    const size_t npx = (size_t)W * H;
+    const int eff = mort_camera_effective_spp(&cam);
 
-    mort_ctx *ctx = NULL;
-    int st = mort_hip_init(device, &ctx);
-    if (st != MORT_OK) die(NULL, st, "mort_hip_init");
-    if ((st = mort_hip_upload_world(ctx, &world)) != MORT_OK) die(ctx, st, "mort_hip_upload_world");
-
-    size_t npx = (size_t)W * H;
-    if (sin) {
-        mort_rng_state *s = malloc(npx * sizeof *s);
-        FILE *f = fopen(sin, "rb");
-        if (!s || !f || fread(s, sizeof *s, npx, f) != npx) { fprintf(stderr, "cannot read %zu states from %s\n", npx, sin); return EXIT_FAILURE; }
-        fclose(f);
-        if ((st = mort_hip_rng_load(ctx, s, W, H)) != MORT_OK) die(ctx, st, "mort_hip_rng_load");
-        free(s);
-    } else if ((st = mort_hip_rng_seed(ctx, seed, W, H)) != MORT_OK) die(ctx, st, "mort_hip_rng_seed");
+    /* ---- ranks: fork before anything touches the GPU ---- */
+    int rank = 0;
+    int id_pipe[64][2];
+    pid_t kids[64];
+    uint8_t *shm = NULL; /* --gather shm: rank r writes its rows of the full frame here */
+    if (gpus > 1) {
+        if (gather_shm) {
+            shm = mmap(NULL, npx * 4, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+            if (shm == MAP_FAILED) { perror("mmap"); return EXIT_FAILURE; }
+        }
+        for (int r = 1; r < gpus; r++) if (pipe(id_pipe[r]) != 0) { perror("pipe"); return EXIT_FAILURE; }
+        for (int r = 1; r < gpus; r++) {
+            pid_t p = fork();
+            if (p < 0) { perror("fork"); return EXIT_FAILURE; }
+            if (p == 0) { rank = r; break; }
+            kids[r] = p;
+        }
+        device = n_devices ? devices[rank] : rank;
+    }
 
     uint8_t *rgba = calloc(npx, 4);
     float *accum = dump ? calloc(npx * 3, sizeof(float)) : NULL;
-    double total_ms = 0;
+    if (!rgba || (dump && !accum)) { fprintf(stderr, "out of memory\n"); return EXIT_FAILURE; }
     mort_stats stats;
-    for (int f = 0; f < frames; f++) {
-        if ((st = mort_hip_render(ctx, &cam, mode, rgba, accum, NULL, &stats)) != MORT_OK) die(ctx, st, "mort_hip_render");
-        total_ms += stats.seconds * 1e3;
-        printf("Avg. time per frame: %3.1f ms\n", total_ms / (f + 1)); /* mort.cu:119 */
+    memset(&stats, 0, sizeof stats);
+    double total_ms = 0, frame_wall = 0;
+    mort_ctx *ctx = NULL;
+    mort_rng_state *hstates = NULL;
+    int st;
+
+    if (host_mode) { /* ---- the kernel body as a host loop: no GPU ---- */
+        hstates = malloc(npx * sizeof *hstates);
+        if (!hstates) { fprintf(stderr, "out of memory\n"); return EXIT_FAILURE; }
+        if (sin) {
+            FILE *f = fopen(sin, "rb");
+            if (!f || fread(hstates, sizeof *hstates, npx, f) != npx) { fprintf(stderr, "cannot read %zu states from %s\n", npx, sin); return EXIT_FAILURE; }
+            fclose(f);
+        } else if ((st = mort_hip_rng_seed_host(seed, W, H, hstates)) != MORT_OK) die(NULL, st, "mort_hip_rng_seed_host");
+        for (int f = 0; f < frames; f++) {
+            if ((st = mort_hip_render_host(&world, &cam, hstates, threads, tree ? MORT_HOST_TREE : 0, rgba, accum, NULL, &stats)) != MORT_OK) die(NULL, st, "mort_hip_render_host");
+            total_ms += stats.seconds * 1e3;
+            printf("Avg. time per frame: %3.1f ms\n", total_ms / (f + 1)); /* mort.cu:119 */
+        }
+        frame_wall = stats.seconds;
+    } else {
+        st = mort_hip_init(device, &ctx);
+        if (st != MORT_OK) die(NULL, st, "mort_hip_init");
+        if (gpus > 1) {
+            mort_partition part = {rank, gpus, 8};
+            if ((st = mort_hip_set_partition(ctx, &part)) != MORT_OK) die(ctx, st, "mort_hip_set_partition");
+            if (!gather_shm) { /* rank 0 makes the RCCL id, the others read it from their pipe */
+                unsigned char id[MORT_COMM_ID_BYTES];
+                if (rank == 0) {
+                    if ((st = mort_hip_comm_id(id)) != MORT_OK) die(ctx, st, "mort_hip_comm_id");
+                    for (int r = 1; r < gpus; r++) if (write(id_pipe[r][1], id, sizeof id) != (ssize_t)sizeof id) { perror("write"); return EXIT_FAILURE; }
+                } else if (read(id_pipe[rank][0], id, sizeof id) != (ssize_t)sizeof id) { perror("read"); return EXIT_FAILURE; }
+                if ((st = mort_hip_comm_init(ctx, id, rank, gpus)) != MORT_OK) die(ctx, st, "mort_hip_comm_init");
+            }
+        }
+        if ((st = mort_hip_upload_world(ctx, &world)) != MORT_OK) die(ctx, st, "mort_hip_upload_world");
+        if (sin) {
+            mort_rng_state *s = malloc(npx * sizeof *s);
+            FILE *f = fopen(sin, "rb");
+            if (!s || !f || fread(s, sizeof *s, npx, f) != npx) { fprintf(stderr, "cannot read %zu states from %s\n", npx, sin); return EXIT_FAILURE; }
+            fclose(f);
+            if ((st = mort_hip_rng_load(ctx, s, W, H)) != MORT_OK) die(ctx, st, "mort_hip_rng_load");
+            free(s);
+        } else if ((st = mort_hip_rng_seed(ctx, seed, W, H)) != MORT_OK) die(ctx, st, "mort_hip_rng_seed");
+
+        for (int f = 0; f < frames; f++) {
+            const double t0 = now_s();
+            if (gpus > 1 && !gather_shm) {
+                if ((st = mort_hip_render_gather(ctx, &cam, mode, rank == 0 ? rgba : NULL, &stats)) != MORT_OK) die(ctx, st, "mort_hip_render_gather");
+            } else {
+                if ((st = mort_hip_render(ctx, &cam, mode, rgba, accum, NULL, &stats)) != MORT_OK) die(ctx, st, "mort_hip_render");
+                if (gpus > 1) { /* --gather shm: owned rows into the shared frame */
+                    const int lr = mort_hip_local_rows(ctx, H);
+                    for (int ly = 0; ly < lr; ly++) { const int y = mort_hip_global_row(ctx, ly); memcpy(shm + (size_t)y * W * 4, rgba + (size_t)y * W * 4, (size_t)W * 4); }
+                }
+            }
+            frame_wall = now_s() - t0;
+            total_ms += stats.seconds * 1e3;
+            if (rank == 0) printf("Avg. time per frame: %3.1f ms\n", total_ms / (f + 1)); /* mort.cu:119 */
+        }
     }
-    int eff = mort_camera_effective_spp(&cam);
-    printf("{\"scene\": %d, \"width\": %d, \"height\": %d, \"spp_nominal\": %d, \"spp_effective\": %d, \"depth\": %d, "
-           "\"seconds\": %.6f, \"msamples_per_s\": %.3f, \"segments\": %llu, \"segments_per_s\": %.4g, "
-           "\"algorithmic_hbm_bytes\": %llu, \"hbm_GBps\": %.4g, \"hbm_frac_of_8TBps\": %.3g, \"reference_walks\": %llu}\n",
-           scene, W, H, cam.samples_per_pixel, eff, cam.bounce_limit, stats.seconds,
-           (double)npx * eff / stats.seconds / 1e6, (unsigned long long)stats.segments, stats.segments / stats.seconds,
+
+    /* ---- ranks other than 0 are done; rank 0 waits for them (their rows are in shm / were gathered) ---- */
+    if (rank != 0) {
+        if (ctx) mort_hip_shutdown(ctx);
+        _exit(0);
+    }
+    int failed = 0;
+    for (int r = 1; r < gpus; r++) { int ws = 0; if (waitpid(kids[r], &ws, 0) < 0 || !WIFEXITED(ws) || WEXITSTATUS(ws) != 0) failed = 1; }
+    if (failed) { fprintf(stderr, "a rank failed\n"); return EXIT_FAILURE; }
+    if (gpus > 1 && gather_shm) {
+        const int lr = mort_hip_local_rows(ctx, H); /* rank 0's own rows are already in rgba; take the others from the mapping */
+        uint8_t *own = malloc(npx * 4);
+        memcpy(own, rgba, npx * 4);
+        memcpy(rgba, shm, npx * 4);
+        for (int ly = 0; ly < lr; ly++) { const int y = mort_hip_global_row(ctx, ly); memcpy(rgba + (size_t)y * W * 4, own + (size_t)y * W * 4, (size_t)W * 4); }
+        free(own);
+    }
+
+    const double sec = (gpus > 1) ? frame_wall : stats.seconds; /* multi-GPU: wall clock of the frame on rank 0, gather included */
+    printf("{\"scene\": %d, \"width\": %d, \"height\": %d, \"spp_nominal\": %d, \"spp_effective\": %d, \"depth\": %d, \"mode\": \"%s\", \"gpus\": %d, "
+           "\"seconds\": %.6f, \"msamples_per_s\": %.3f, \"kernel_seconds\": %.6f, \"gather_seconds\": %.6f, \"segments\": %llu, "
+           "\"algorithmic_hbm_bytes\": %llu, \"hbm_GBps\": %.4g, \"hbm_frac_of_8TBps\": %.3g, \"reference_walks\": %llu, \"kernel\": \"%s\"}\n",
+           scene, W, H, cam.samples_per_pixel, eff, cam.bounce_limit, host_mode ? "host" : mode == MORT_MODE_WAVE ? "wave" : "mega", gpus, sec,
+           (double)npx * eff / sec / 1e6, stats.seconds, stats.gather_seconds, (unsigned long long)stats.segments,
            (unsigned long long)stats.algorithmic_hbm_bytes, stats.algorithmic_hbm_bytes / stats.seconds / 1e9,
-           stats.algorithmic_hbm_bytes / stats.seconds / 8e12, (unsigned long long)stats.reference_walks);
+           stats.algorithmic_hbm_bytes / stats.seconds / 8e12, (unsigned long long)stats.reference_walks, stats.kernel_name);
     if (out && mort_write_ppm(out, rgba, W, H) != 0) { fprintf(stderr, "cannot write %s\n", out); return EXIT_FAILURE; }
     if (dump) {
         FILE *f = fopen(dump, "wb");
@@ -109,15 +247,15 @@ int main(int argc, char **argv) {
         fclose(f);
     }
     if (sout) {
-        mort_rng_state *s = malloc(npx * sizeof *s);
-        if ((st = mort_hip_rng_store(ctx, s, W, H)) != MORT_OK) die(ctx, st, "mort_hip_rng_store");
+        mort_rng_state *s = hstates ? hstates : malloc(npx * sizeof *s);
+        if (!hstates && (st = mort_hip_rng_store(ctx, s, W, H)) != MORT_OK) die(ctx, st, "mort_hip_rng_store");
         FILE *f = fopen(sout, "wb");
         if (!f || fwrite(s, sizeof *s, npx, f) != npx) { fprintf(stderr, "cannot write %s\n", sout); return EXIT_FAILURE; }
         fclose(f);
-        free(s);
+        if (!hstates) free(s);
     }
-    mort_hip_shutdown(ctx);
+    if (ctx) mort_hip_shutdown(ctx);
     mort_world_free(&world);
-    free(texels); free(rgba); free(accum);
+    free(texels); free(rgba); free(accum); free(hstates);
     return 0;
 }

@@ -29,6 +29,7 @@
 #include "scene_blob.h"
 #include "seed_host.h"
 #include "mort_internal.h"
+#include "mort_ctx.h"
 #include "mega_gen.h"
 #include "wave_gen.h"
 
@@ -102,67 +103,6 @@ seed_kernel(const SeedArgs a) {
 /* ====================================================================== host */
 
 
-struct mort_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::string last_error;
-    /* scene */
-    void *d_scene = nullptr;
-    DScene sc{};
-    bool have_world = false;
-    std::vector<int> list_types, list_idxs;        /* host copy, to validate the light object at render */
-    int list_first[MORT_NUM_HITTABLE_LIST]{}, list_count[MORT_NUM_HITTABLE_LIST]{};
-    int n_wspheres = 0, n_wquads = 0, n_lists = 0;
-    /* partition */
-    mort_partition part{0, 1, 8};
-    /* rng */
-    mort_rng_state *d_states = nullptr;
-    int rng_w = 0, rng_h = 0, rng_local_rows = 0;
-    uint32_t *d_seqmats = nullptr;
-    /* scratch */
-    void *d_rgba = nullptr, *d_accum = nullptr, *d_segpx = nullptr;
-    size_t rgba_cap = 0, accum_cap = 0, segpx_cap = 0;
-    unsigned long long *d_counters = nullptr; /* [0] segments, [1] rng draws, [2] work counter */
-    bool wave_ok = false; /* wavefront mode: one BVH over spheres as the whole world, hot blob fits LDS */
-    /* BVH megakernel: its own LDS image (own tree, reference leaf records, spheres, material / texture tables) */
-    void *d_fast = nullptr;
-    uint32_t f_nodes2 = 0, f_leaves = 0, f_spheres = 0, f_lambert = 0, f_metal = 0, f_diel = 0, f_dlight = 0, f_iso = 0,
-             f_solid = 0, f_checker = 0, fast_bytes = 0;
-    int own_nodes = 0, own_leaves = 0;
-    bool fast_ok = false;
-    /* unified-tree megakernel (mega_gen.hip): its LDS image and launch constants */
-    void *d_gen = nullptr;
-    uint32_t gen_bytes = 0;
-    GenArgs gen{};
-    bool gen_ok = false;
-    int gen_prims = 0; /* solid primitives in the unified tree */
-    float gen_lo[3] = {0, 0, 0}, gen_hi[3] = {0, 0, 0}, gen_reach = 0;
-    int num_cus = 256;
-    /* pixel-tile ordering of the BVH megakernel: most expensive tiles first (cost = segments of the previous
-     * frame with this geometry, or of a 1-sample probe) so the frame does not end on its longest pixel chains */
-    unsigned *d_tile_cost = nullptr, *d_tile_order = nullptr;
-    mort_rng_state *d_probe_states = nullptr;
-    size_t tile_cap = 0, probe_cap = 0;
-    unsigned long long cost_key = 0; /* hash of the (world, geometry, partition, camera basis) the costs in d_tile_cost belong to; 0 = none */
-    unsigned world_serial = 0;       /* bumped by upload_world: part of cost_key */
-    unsigned *d_tile_keys = nullptr, *d_tile_iota = nullptr; /* device argsort scratch (tile_sort.hip) */
-    void *d_sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
-    hipStream_t last_stream = nullptr; /* stream of the most recent render launch (may be the caller's) */
-    /* wavefront mode work buffers */
-    void *d_wf = nullptr;
-    size_t wf_bytes = 0;
-    unsigned *h_live = nullptr; /* pinned */
-    int wf_fronts = 0;          /* fronts of the last wavefront render (reported) */
-};
-
-static int hip_fail(mort_ctx *c, hipError_t e, const char *what) {
-    if (c) c->last_error = std::string(what) + ": " + hipGetErrorString(e);
-    return MORT_ERR_HIP;
-}
-#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(ctx, e_, #call); } while (0)
-
 /* Wait for everything this context has launched: its own stream and, if a render went to a caller's stream, that one
  * too -- before any call that reads, overwrites or frees what a render kernel uses (states, scene, counters). */
 static hipError_t quiesce(mort_ctx *c) {
@@ -235,6 +175,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     quiesce(c);
+    mort_hip_comm_destroy(c);
     hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
     hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);

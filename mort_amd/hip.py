@@ -24,6 +24,7 @@ EXPORTS = [
     "mort_hip_strerror", "mort_hip_last_error", "mort_hip_init", "mort_hip_shutdown", "mort_hip_upload_world",
     "mort_hip_set_partition", "mort_hip_rng_seed", "mort_hip_rng_load", "mort_hip_rng_store", "mort_hip_render",
     "mort_hip_render_device", "mort_hip_local_rows", "mort_hip_global_row", "mort_hip_rng_seed_host", "mort_hip_render_host",
+    "mort_hip_comm_id", "mort_hip_comm_init", "mort_hip_comm_destroy", "mort_hip_render_gather", "mort_hip_comm_selftest",
 ]
 HOST_TREE = 1
 
@@ -36,7 +37,7 @@ class Stats(C.Structure):
     _fields_ = [("seconds", C.c_double), ("segments", C.c_uint64), ("pixels", C.c_uint64),
                 ("eff_samples", C.c_uint64), ("rng_draws", C.c_uint64), ("algorithmic_hbm_bytes", C.c_uint64),
                 ("scene_in_lds", C.c_int), ("local_rows", C.c_int), ("kernel_vgprs", C.c_int),
-                ("kernel_lds_bytes", C.c_int), ("reference_walks", C.c_uint64), ("kernel_name", C.c_char * 64)]
+                ("kernel_lds_bytes", C.c_int), ("reference_walks", C.c_uint64), ("kernel_name", C.c_char * 64), ("gather_seconds", C.c_double)]
 
     def asdict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

@@ -1,0 +1,140 @@
+"""The `mort` binary -- the named drop-in surface (mort.cu:633-725: `mort <scene_id>`) -- run as a program.
+
+CPU tests: usage / argument errors, `--mode host` (BASELINE config 1 as stated: Scene 1 200x112, 4 spp, host-side
+serial loop) against the golden vectors and the oracle through the files it writes (PPM, fp32 dump, state dump) and
+through tools/mort_diff.py.  GPU tests: the same files from the HIP path, `--gpus 2` with both ranks on the one GPU
+(`--gather shm`; RCCL needs one GPU per rank and is exercised by bench.py on a multi-GPU node), wavefront mode on the
+final scene, and the default earth texture."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from mort_amd import host
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+MORT = os.path.join(ROOT, "mort_amd", "bin", "mort")
+DIFF = os.path.join(ROOT, "tools", "mort_diff.py")
+GOLD = np.load(os.path.join(HERE, "golden", "oracle_golden.npz"))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not os.path.exists(MORT):
+        subprocess.check_call(["make", "-C", ROOT, "host", "hip", "cli"])
+
+
+def run(*args, cwd=ROOT, check=True):
+    p = subprocess.run([MORT, *map(str, args)], cwd=cwd, capture_output=True, text=True, timeout=600)
+    if check:
+        assert p.returncode == 0, p.stdout + p.stderr
+    return p
+
+
+def read_ppm(path):
+    data = open(path, "rb").read()
+    hdr, rest = data.split(b"255\n", 1)
+    w, h = int(hdr.split()[1]), int(hdr.split()[2])
+    return np.frombuffer(rest, dtype=np.uint8, count=w * h * 3).reshape(h, w, 3)[::-1]  # file rows are top-down, buffer rows bottom-up
+
+
+def last_json(p):
+    return json.loads(p.stdout.strip().splitlines()[-1])
+
+
+def test_usage_and_argument_errors():
+    p = run(check=False)
+    assert p.returncode != 0 and p.stdout.startswith("Usage: mort <number_between_1_and_10>")  # mort.cu:638-641
+    assert run(1, "--bogus", check=False).returncode != 0
+    assert run(1, "--mode", "nonsense", check=False).returncode != 0
+    assert run(1, "--mode", "host", "--gpus", 2, check=False).returncode != 0
+    p = run(3, "--mode", "host", "--earth", "/nonexistent/earth.jpg", "--width", 16, "--spp", 1, check=False)
+    assert p.returncode != 0 and "Could not load image file" in p.stderr  # img_loader.h:33
+
+
+def test_config1_host_mode_files(tmp_path, oracle):
+    """BASELINE config 1: `mort 1 --width 200 --spp 4 --mode host` (one thread): image, accumulators and final streams."""
+    ppm, raw, stf = tmp_path / "c1.ppm", tmp_path / "c1.raw", tmp_path / "c1.states"
+    p = run(1, "--width", 200, "--spp", 4, "--mode", "host", "--out", ppm, "--dump-f32", raw, "--states-out", stf)
+    j = last_json(p)
+    assert j["mode"] == "host" and (j["width"], j["height"], j["spp_effective"]) == (200, 112, 4) and "Avg. time per frame" in p.stdout
+    assert (read_ppm(ppm) == GOLD["s1_c1_rgba"][..., :3]).all()
+    acc = np.fromfile(raw, dtype=np.float32).reshape(112, 200, 3)
+    assert (acc.view(np.uint32) == GOLD["s1_c1_accum"].view(np.uint32)).all()
+    world, cam = host.build_scene(1, width=200, spp=4)
+    ref = oracle.render(world, cam, nthreads=4)
+    st = np.fromfile(stf, dtype=oracle.STATE_DTYPE)
+    assert (st["d"] == ref["states"]["d"]).all() and (st["v"] == ref["states"]["v"]).all() and j["segments"] == ref["segments"]
+    # the comparison tool on the files: identical -> exit 0; against a different render -> exit 1
+    other = tmp_path / "other.raw"
+    run(1, "--width", 200, "--spp", 4, "--mode", "host", "--seed", 7, "--dump-f32", other, "--threads", 4)
+    assert subprocess.run([sys.executable, DIFF, str(raw), str(raw), "--f32", "200", "112"], capture_output=True).returncode == 0
+    assert subprocess.run([sys.executable, DIFF, str(raw), str(other), "--f32", "200", "112"], capture_output=True).returncode == 1
+
+
+def test_host_mode_tree_threads_and_state_files(tmp_path, oracle):
+    """Final scene through the host loop with the unified tree, two frames chained through a state file; the default
+    earth texture (tests/golden/earthmap.jpg through the product's JPEG decoder) is found from another directory."""
+    s1, ppm = tmp_path / "f1.states", tmp_path / "f2.ppm"
+    run(9, "--width", 40, "--spp", 4, "--mode", "host", "--tree", "--threads", 4, "--states-out", s1, cwd=str(tmp_path))
+    p = run(9, "--width", 40, "--spp", 4, "--mode", "host", "--tree", "--threads", 3, "--states-in", s1, "--out", ppm, cwd=str(tmp_path))
+    assert "unified tree" in last_json(p)["kernel"]
+    world, cam = host.build_scene(9, width=40, spp=4)
+    r1 = oracle.render(world, cam, nthreads=8)
+    r2 = oracle.render(world, cam, nthreads=8, states=r1["states"].copy())
+    assert (read_ppm(ppm) == r2["rgba"][..., :3]).all()
+
+
+@pytest.mark.gpu
+def test_gpu_cli_files_match_oracle(tmp_path, oracle):
+    ppm, raw, stf = tmp_path / "g.ppm", tmp_path / "g.raw", tmp_path / "g.states"
+    p = run(1, "--width", 200, "--spp", 4, "--out", ppm, "--dump-f32", raw, "--states-out", stf)
+    j = last_json(p)
+    assert j["mode"] == "mega" and j["kernel"].startswith("mega_bvh_kernel")
+    world, cam = host.build_scene(1, width=200, spp=4)
+    ref = oracle.render(world, cam, nthreads=8)
+    assert (read_ppm(ppm) == ref["rgba"][..., :3]).all()
+    assert (np.fromfile(raw, dtype=np.float32).reshape(112, 200, 3).view(np.uint32) == ref["accum"].view(np.uint32)).all()
+    st = np.fromfile(stf, dtype=oracle.STATE_DTYPE)
+    assert (st["v"] == ref["states"]["v"]).all() and j["segments"] == ref["segments"]
+    # host mode and GPU mode write identical files
+    hraw = tmp_path / "h.raw"
+    run(1, "--width", 200, "--spp", 4, "--mode", "host", "--threads", 8, "--dump-f32", hraw)
+    assert subprocess.run([sys.executable, DIFF, str(raw), str(hraw), "--f32", "200", "112"], capture_output=True).returncode == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,extra", [(1, []), (8, ["--depth", "6"]), (6, ["--mode", "wave"])])
+def test_gpu_cli_two_ranks_compose_the_single_gpu_frame(tmp_path, scene, extra):
+    """`--gpus 2`: two forked ranks (both on device 0 here, rows gathered through the shared mapping) = one rank."""
+    one, two = tmp_path / "one.ppm", tmp_path / "two.ppm"
+    run(scene, "--width", 96, "--spp", 4, "--out", one, *extra)
+    p = run(scene, "--width", 96, "--spp", 4, "--gpus", 2, "--devices", "0,0", "--gather", "shm", "--out", two, *extra)
+    assert last_json(p)["gpus"] == 2
+    assert (read_ppm(one) == read_ppm(two)).all()
+
+
+@pytest.mark.gpu
+def test_gpu_cli_final_scene_wavefront_and_default_earth(tmp_path, oracle):
+    """BASELINE config 5's command shape (`mort 8 --mode wave`, here 64x64 x 4 spp) with the earth texture found by default."""
+    ppm = tmp_path / "w.ppm"
+    p = run(8, "--width", 64, "--spp", 4, "--mode", "wave", "--out", ppm, cwd=str(tmp_path))
+    assert last_json(p)["kernel"].startswith("wf_trav_gen")
+    world, cam = host.build_scene(8, width=64, spp=4)
+    assert (read_ppm(ppm) == oracle.render(world, cam, nthreads=16)["rgba"][..., :3]).all()
+
+
+@pytest.mark.gpu
+def test_rccl_path_one_rank_rehearsal(gpu_ctx):
+    """librccl loads, a communicator forms, a grouped ncclSend / ncclRecv of uchar rows on the context's stream returns
+    the same bytes through the de-interleave kernel (one rank sending to itself: all a one-GPU box can host)."""
+    import ctypes as C
+    from mort_amd import hip
+    L = hip.lib()
+    L.mort_hip_comm_selftest.argtypes = [C.c_void_p]; L.mort_hip_comm_selftest.restype = C.c_int
+    st = L.mort_hip_comm_selftest(gpu_ctx._h)
+    assert st == 0, L.mort_hip_last_error(gpu_ctx._h).decode()
