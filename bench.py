@@ -85,7 +85,7 @@ def profile_figures(tag, kernel_substr):
         c = {}
         for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_pmc_sq_summary.csv"))):
             if kernel_substr in r["kernel"] and "true" not in r["kernel"].split("<")[-1].split()[1:2]:
-                c.setdefault(r["counter"], float(r["per_dispatch"]))
+                c.setdefault(r["counter"], float(r.get("max_dispatch") or r["per_dispatch"]))
         # 1024 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines; a VALU instruction holds its SIMD for 4 cycles
         out["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0)
         out["valu_lane_occupancy"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)

@@ -12,15 +12,16 @@ tot = {}
 for r in rows:
     if "true" in r["kernel"].split("<")[-1].split()[1:2]:
         continue  # the one-sample cost probe
-    tot.setdefault(r["kernel"], {})[r["counter"]] = (float(r["sum_over_dispatches"]), int(r["dispatches"]))
+    # (value, divisor): the frame's own dispatch = the largest one (a one-sample cost probe of the same kernel may precede it)
+    tot.setdefault(r["kernel"], {})[r["counter"]] = (float(r.get("max_dispatch") or r["sum_over_dispatches"]), 1 if r.get("max_dispatch") else int(r["dispatches"]))
 kern = max(tot, key=lambda k: sum(v[0] for v in tot[k].values()))
 f, nf = tot[kern].get("FETCH_SIZE", (0.0, 1))
 w, nw = tot[kern].get("WRITE_SIZE", (0.0, 1))
 wave = mode == "wave"
 # wavefront mode: one render = many launches; report per render (all launches of all wf_ kernels)
 if wave:
-    f = sum(v.get("FETCH_SIZE", (0, 1))[0] for k, v in tot.items() if "wf_" in k)
-    w = sum(v.get("WRITE_SIZE", (0, 1))[0] for k, v in tot.items() if "wf_" in k)
+    f = sum(float(r["sum_over_dispatches"]) for r in rows if "wf_" in r["kernel"] and r["counter"] == "FETCH_SIZE")
+    w = sum(float(r["sum_over_dispatches"]) for r in rows if "wf_" in r["kernel"] and r["counter"] == "WRITE_SIZE")
     nf = nw = 1
     kern = "wf_* (all launches of one render)"
 import math

@@ -1,21 +1,26 @@
-"""Time one rank's share of the headline frame for N-way partitions on a single GPU (rehearsal of the
-multi-GPU scaling run: the slowest rank bounds the frame).  usage: time_partition.py [N ...]"""
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mort_amd import host, hip
-world, cam = host.build_scene(1, spp=int(os.environ.get("SPP", "500")))
-ctx = hip.Context(0)
-ctx.upload_world(world)
-ns = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
-base = float(os.environ.get("BASE_MS", "0")) * 1e-3 or None
-for n in ns:
-    worst = 0.0
-    ranks = range(n) if os.environ.get("ALL_RANKS") else [0, n - 1] if n > 1 else [0]
-    for r in ranks:
-        ctx.set_partition(r, n, 8)
-        ctx.rng_seed(69420, cam.image_width, cam.image_height)
-        out = ctx.render(cam, want_accum=False)  # first frame: tiles ordered by the one-sample probe
-        out = ctx.render(cam, want_accum=False)  # steady state: ordered by the previous frame's costs
-        worst = max(worst, out["stats"]["seconds"])
-    base = base or worst * n
-    print(f"N={n}: slowest rank {worst*1e3:.1f} ms  -> scaling efficiency {base / (n * worst) * 100:.1f}%  lds={out['stats']['kernel_lds_bytes']}", flush=True)
+#!/usr/bin/env python3
+"""One rank of an N-way row partition timed on a single MI355X, N = 1, 2, 4, 8: the kernel-time part of strong scaling
+(the gather is a 0.4 MB point-to-point copy per peer).  Prints one JSON object (kept under profiles/).
+usage: time_partition.py [SCENE WIDTH SPP]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mort_amd import host, hip, structs as S
+sid, width, spp = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1, 1200, 500)
+world, cam = host.build_scene(sid, width=width, spp=spp)
+W, H = cam.image_width, cam.image_height
+out = {"scene": sid, "width": W, "height": H, "spp": spp, "note": "steady-state frame (third of three) of the first and the last rank of each partition, one GPU", "ranks": {}}
+for n in (1, 2, 4, 8):
+    times = []
+    for r in sorted({0, n - 1}):
+        with hip.Context(0) as ctx:
+            ctx.set_partition(r, n, 8)
+            ctx.upload_world(world)
+            ctx.rng_seed(S.DEFAULT_SEED, W, H)
+            for f in range(3):
+                st = ctx.render(cam, want_accum=False)["stats"]
+            times.append({"rank": r, "ms": st["seconds"] * 1e3, "segments": st["segments"], "kernel": st["kernel_name"]})
+    out["ranks"][str(n)] = times
+t1 = max(t["ms"] for t in out["ranks"]["1"])
+out["summary"] = {str(n): {"ms_slowest_rank": max(t["ms"] for t in out["ranks"][str(n)]), "efficiency_from_kernel_time": t1 / (n * max(t["ms"] for t in out["ranks"][str(n)]))} for n in (1, 2, 4, 8)}
+print(json.dumps(out, indent=1))
