@@ -456,3 +456,15 @@ def test_async_render_device_then_store(gpu_ctx, oracle):
     tile2 = torch.zeros((cam2.image_height, cam2.image_width, 4), dtype=torch.uint8, device="cuda:0")
     gpu_ctx.render_device(cam2, tile2.data_ptr(), 0, stream.cuda_stream, sync=True)
     assert (tile2.cpu().numpy() == oracle.render(world2, cam2, nthreads=8)["rgba"]).all()
+
+
+def test_right_to_left_host_profile(gpu_ctx, oracle):
+    """The reference leaves the evaluation order of sibling random_float() arguments to the compiler (mort.cu:147,152,164;
+    vec3.cuh:63-69): the host layer's right-to-left profile builds a different Scene 1 / final scene; the HIP path must
+    match the oracle on those worlds too (VERDICT r1 #7)."""
+    for sid, width, spp in ((1, 160, 4), (9, 64, 4)):
+        world, cam = host.build_scene(sid, width=width, spp=spp, args_rtl=1)
+        w0, _ = host.build_scene(sid, width=width, spp=spp)
+        ref = oracle.render(world, cam, nthreads=8)
+        assert not (ref["rgba"] == oracle.render(w0, cam, nthreads=8)["rgba"]).all()  # it IS a different world
+        assert_same(render_gpu(gpu_ctx, world, cam, oracle=oracle), ref)
