@@ -84,6 +84,13 @@ void mort_rotated_smoke_box(mort_world *w, mort_vec3 size, mort_vec3 translation
 /* ---- camera ---- */
 void mort_camera_defaults(mort_camera *cam);    /* in-class initialisers, camera.cuh:13-43 */
 void mort_camera_initialize(mort_camera *cam);  /* camera.cuh:47-84 */
+/* One idle tick of the reference's input() (mort.cu:49-91: W/S/A/D move lookfrom and lookat one unit along the camera basis,
+ * dragging with the left button turns lookat by -delta / 500 rad about vup / u), then initialize(): scripted, headless. */
+#define MORT_KEY_W 1
+#define MORT_KEY_S 2
+#define MORT_KEY_A 4
+#define MORT_KEY_D 8
+void mort_camera_input(mort_camera *cam, int keys, int mouse_dx, int mouse_dy, int left_button);
 /* effective samples per pixel: floor(sqrt(spp))^2 (camera.cuh:51,187-188) */
 int mort_camera_effective_spp(const mort_camera *cam);
 

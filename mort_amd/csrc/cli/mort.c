@@ -8,6 +8,11 @@
  *                   [--mode mega|wave|host] [--threads T] [--tree]       host: the kernel body as a host loop (no GPU)
  *                   [--gpus N] [--devices a,b,..] [--gather rccl|shm]     one process per GPU, rows partitioned, one gather
  *                   [--out f.ppm] [--dump-f32 f.raw] [--states-in f] [--states-out f] [--earth img] [--rtl] [--device K]
+ *                   [--keys WASD..] [--mouse dx,dy]        the reference's interactive loop, scripted: one idle tick per frame
+ *
+ * --frames N re-renders like the reference's idle loop (mort.cu:93-120): RNG streams continue from frame to frame; before each
+ * frame after the first, input() runs (mort.cu:49-91) with the frame's character of --keys held down ('.' = none) and the
+ * --mouse delta dragged with the left button.  --out / --dump-f32 hold the last frame.
  *
  * --gpus N: N - 1 ranks are forked BEFORE any HIP call (a process that has initialised the GPU must not fork or exec);
  * rank r renders row blocks r, r + N, ... on device r (or --devices) and the packed rows are gathered to rank 0 -- over
@@ -35,7 +40,7 @@ static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &
 static int usage(void) {
     printf("Usage: mort <number_between_1_and_10> [--width W] [--aspect A] [--spp N] [--depth D] [--seed S] [--frames N] "
            "[--mode mega|wave|host] [--threads T] [--tree] [--gpus N] [--devices a,b,..] [--gather rccl|shm] "
-           "[--out f.ppm] [--dump-f32 f.raw] [--states-in f] [--states-out f] [--earth image.jpg|.ppm] [--rtl] [--device K]\n");
+           "[--out f.ppm] [--dump-f32 f.raw] [--states-in f] [--states-out f] [--earth image.jpg|.ppm] [--rtl] [--device K] [--keys WASD..] [--mouse dx,dy]\n");
     return -1;
 }
 
@@ -59,6 +64,16 @@ static unsigned char *load_earth(const char *path, const char *argv0, int *w, in
     return NULL;
 }
 
+/* input() before frame f (mort.cu:49-91,94): the f-th character of --keys held down, the --mouse delta dragged */
+static void frame_input(mort_camera *cam, const char *keys, int f, int mdx, int mdy) {
+    int k = 0;
+    if (keys && (size_t)(f - 1) < strlen(keys)) {
+        const char ch = keys[f - 1];
+        k = (ch == 'W' || ch == 'w') ? MORT_KEY_W : (ch == 'S' || ch == 's') ? MORT_KEY_S : (ch == 'A' || ch == 'a') ? MORT_KEY_A : (ch == 'D' || ch == 'd') ? MORT_KEY_D : 0;
+    }
+    if (k || mdx || mdy) mort_camera_input(cam, k, mdx, mdy, (mdx || mdy) ? 1 : 0);
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) return usage();
     int scene = atoi(argv[1]);
@@ -66,7 +81,8 @@ int main(int argc, char **argv) {
     int gpus = 1, gather_shm = 0, devices[64], n_devices = 0;
     double aspect = 0;
     unsigned long long seed = MORT_DEFAULT_SEED;
-    const char *out = NULL, *dump = NULL, *sin = NULL, *sout = NULL, *earth = NULL;
+    const char *out = NULL, *dump = NULL, *sin = NULL, *sout = NULL, *earth = NULL, *keys = NULL;
+    int mouse_dx = 0, mouse_dy = 0;
     for (int i = 2; i < argc; i++) {
 #define ARG(name) (strcmp(argv[i], name) == 0 && i + 1 < argc)
         if (ARG("--width")) width = atoi(argv[++i]);
@@ -80,6 +96,8 @@ int main(int argc, char **argv) {
         else if (ARG("--states-out")) sout = argv[++i];
         else if (ARG("--earth")) earth = argv[++i];
         else if (ARG("--frames")) frames = atoi(argv[++i]);
+        else if (ARG("--keys")) keys = argv[++i];
+        else if (ARG("--mouse")) { if (sscanf(argv[++i], "%d,%d", &mouse_dx, &mouse_dy) != 2) { fprintf(stderr, "--mouse dx,dy\n"); return -1; } }
         else if (ARG("--device")) device = atoi(argv[++i]);
         else if (ARG("--threads")) threads = atoi(argv[++i]);
         else if (ARG("--gpus")) gpus = atoi(argv[++i]);
@@ -168,6 +186,7 @@ int main(int argc, char **argv) {
             fclose(f);
         } else if ((st = mort_hip_rng_seed_host(seed, W, H, hstates)) != MORT_OK) die(NULL, st, "mort_hip_rng_seed_host");
         for (int f = 0; f < frames; f++) {
+            if (f > 0) frame_input(&cam, keys, f, mouse_dx, mouse_dy);
             if ((st = mort_hip_render_host(&world, &cam, hstates, threads, tree ? MORT_HOST_TREE : 0, rgba, accum, NULL, &stats)) != MORT_OK) die(NULL, st, "mort_hip_render_host");
             total_ms += stats.seconds * 1e3;
             printf("Avg. time per frame: %3.1f ms\n", total_ms / (f + 1)); /* mort.cu:119 */
@@ -199,6 +218,7 @@ int main(int argc, char **argv) {
         } else if ((st = mort_hip_rng_seed(ctx, seed, W, H)) != MORT_OK) die(ctx, st, "mort_hip_rng_seed");
 
         for (int f = 0; f < frames; f++) {
+            if (f > 0) frame_input(&cam, keys, f, mouse_dx, mouse_dy);
             const double t0 = now_s();
             if (gpus > 1 && !gather_shm) {
                 if ((st = mort_hip_render_gather(ctx, &cam, mode, rank == 0 ? rgba : NULL, &stats)) != MORT_OK) die(ctx, st, "mort_hip_render_gather");

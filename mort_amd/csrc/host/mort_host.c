@@ -517,6 +517,40 @@ static float degrees_to_radians(float degrees) { /* utils.h:21,25-27: float pi *
 }
 static float host_tanf(float x) { return (float)(mort_sin((double)x) / mort_cos((double)x)); }
 
+void mort_camera_initialize(mort_camera *c);
+
+/* rotate_around (vec3.cuh:215-227): `vec` turned by theta about `axis` */
+static mort_vec3 rotate_around(mort_vec3 vec, mort_vec3 axis, float theta) {
+    const mort_vec3 a_parallel_b = v_scale(v_dot(vec, axis) / v_dot(axis, axis), axis);
+    const mort_vec3 a_orthogonal_b = v_sub(vec, a_parallel_b);
+    const mort_vec3 w = v_cross(axis, a_orthogonal_b);
+    const float x1 = (float)mort_cos((double)theta) / v_len(a_orthogonal_b);
+    const float x2 = (float)mort_sin((double)theta) / v_len(w);
+    const mort_vec3 rot = v_scale(v_len(a_orthogonal_b), v_add(v_scale(x1, a_orthogonal_b), v_scale(x2, w)));
+    return v_add(rot, a_parallel_b);
+}
+
+/* One idle tick of the reference's input() (mort.cu:49-91), with the Win32 polling replaced by its result: which of W/S/A/D are
+ * down (MORT_KEY_*), the mouse delta in pixels, and whether the left button is held.  Moves lookfrom / lookat along the camera
+ * basis of the PREVIOUS initialize(), turns lookat about vup / u by -delta / 500 rad, then re-initialises the camera. */
+void mort_camera_input(mort_camera *c, int keys, int mouse_dx, int mouse_dy, int left_button) {
+    if (keys & MORT_KEY_W) { c->lookat = v_add(c->lookat, v_neg(c->w)); c->lookfrom = v_add(c->lookfrom, v_neg(c->w)); }
+    if (keys & MORT_KEY_S) { c->lookat = v_add(c->lookat, c->w); c->lookfrom = v_add(c->lookfrom, c->w); }
+    if (keys & MORT_KEY_A) { c->lookat = v_add(c->lookat, v_neg(c->u)); c->lookfrom = v_add(c->lookfrom, v_neg(c->u)); }
+    if (keys & MORT_KEY_D) { c->lookat = v_add(c->lookat, c->u); c->lookfrom = v_add(c->lookfrom, c->u); }
+    if (left_button) {
+        if (mouse_dx != 0) {
+            const mort_vec3 dir = v_sub(c->lookat, c->lookfrom);
+            c->lookat = v_add(c->lookfrom, rotate_around(dir, c->vup, (float)(-mouse_dx / 500.0)));
+        }
+        if (mouse_dy != 0) {
+            const mort_vec3 dir = v_sub(c->lookat, c->lookfrom);
+            c->lookat = v_add(c->lookfrom, rotate_around(dir, c->u, (float)(-mouse_dy / 500.0)));
+        }
+    }
+    mort_camera_initialize(c);
+}
+
 void mort_camera_initialize(mort_camera *c) { /* camera.cuh:47-84 */
     c->image_height = (int)(c->image_width / c->aspect_ratio);
     c->image_height = (c->image_height < 1) ? 1 : c->image_height;

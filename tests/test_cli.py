@@ -138,3 +138,34 @@ def test_rccl_path_one_rank_rehearsal(gpu_ctx):
     L.mort_hip_comm_selftest.argtypes = [C.c_void_p]; L.mort_hip_comm_selftest.restype = C.c_int
     st = L.mort_hip_comm_selftest(gpu_ctx._h)
     assert st == 0, L.mort_hip_last_error(gpu_ctx._h).decode()
+
+
+def test_scripted_input_frames(tmp_path, oracle):
+    """--frames with --keys / --mouse: the reference's idle loop (mort.cu:49-120) -- input(), initialize(), render with the
+    streams continuing -- against the oracle driven the same way, and mort_camera_input against its closed form."""
+    import ctypes as C
+    L = host.lib()
+    L.mort_camera_input.argtypes = [C.POINTER(type(host.build_scene(10)[1])), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.mort_camera_input.restype = None
+    world, cam = host.build_scene(10, width=64, spp=1)
+    w = np.array(list(cam.w.e)); u = np.array(list(cam.u.e)); lf = np.array(list(cam.lookfrom.e)); la = np.array(list(cam.lookat.e))
+    r1 = oracle.render(world, cam, nthreads=4)
+    L.mort_camera_input(C.byref(cam), 1, 0, 0, 0)  # W: one unit along -w (mort.cu:52-55)
+    assert np.allclose(list(cam.lookfrom.e), lf - w, atol=1e-6) and np.allclose(list(cam.lookat.e), la - w, atol=1e-6)
+    r2 = oracle.render(world, cam, nthreads=4, states=r1["states"].copy())
+    ppm = tmp_path / "f2.ppm"
+    run(10, "--width", 64, "--spp", 1, "--mode", "host", "--frames", 2, "--keys", "W", "--out", ppm)
+    assert (read_ppm(ppm) == r2["rgba"][..., :3]).all() and not (r1["rgba"] == r2["rgba"]).all()
+    # a drag turns lookat about vup by -dx / 500 rad and keeps its distance (vec3.cuh:215-227)
+    before = np.array(list(cam.lookat.e)) - np.array(list(cam.lookfrom.e))
+    L.mort_camera_input(C.byref(cam), 0, 100, 0, 1)
+    after = np.array(list(cam.lookat.e)) - np.array(list(cam.lookfrom.e))
+    assert np.isclose(np.linalg.norm(after), np.linalg.norm(before), rtol=1e-5)
+    up = np.array(list(cam.vup.e))
+    b_perp = before - before.dot(up) / up.dot(up) * up; a_perp = after - after.dot(up) / up.dot(up) * up
+    cosang = b_perp.dot(a_perp) / np.linalg.norm(b_perp) / np.linalg.norm(a_perp)
+    assert np.isclose(np.arccos(np.clip(cosang, -1, 1)), 0.2, atol=1e-4) and np.isclose(before.dot(up), after.dot(up), atol=1e-4)
+    # A / D move along -u / +u
+    lf2 = np.array(list(cam.lookfrom.e)); u2 = np.array(list(cam.u.e))
+    L.mort_camera_input(C.byref(cam), 8, 0, 0, 0)
+    assert np.allclose(list(cam.lookfrom.e), lf2 + u2, atol=1e-5)
