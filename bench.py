@@ -68,6 +68,23 @@ def cpu_baseline(args, threads):
     }
 
 
+def host_loop(args, threads):
+    """The product's own `--mode host` (mort_hip_render_host: the kernel body as a host loop, north_star's CPU figure) on the
+    same bounded sample as cpu_baseline, all threads and one thread.  Reported beside cpu_baseline, never instead of it."""
+    from mort_amd import host, hip
+    cw = args.cpu_width or (args.width if args.scene not in (8, 9) else min(args.width, 160))
+    world, cam = host.build_scene(args.scene, width=cw, spp=args.cpu_spp, depth=args.depth, aspect=args.aspect)
+    tree = args.scene not in (1, 10)
+    out = {}
+    for name, t in (("all_threads", threads), ("one_thread", 1)):
+        if t == 1:
+            world, cam = host.build_scene(args.scene, width=cw if args.scene not in (8, 9) else 48, spp=1, depth=args.depth, aspect=args.aspect)
+        r = hip.render_host(world, cam, nthreads=t, tree=tree, want_accum=False, want_segments=False)["stats"]
+        out[name] = {"value": r["eff_samples"] / r["seconds"] / 1e6, "unit": "Msamples/s", "cores": t, "seconds": r["seconds"],
+                     "sample": f"{cam.image_width}x{cam.image_height} at {cam.samples_per_pixel} spp, {r['segments']} segments ({r['kernel_name']})"}
+    return out
+
+
 def profile_figures(tag, kernel_substr):
     """Counter figures of the profiled configuration, computed from the rocprofv3 summaries committed under
     profiles/ (rocprofv3 cannot run inside this process): HBM traffic per launch, VALU issue fraction and VALU
@@ -239,6 +256,7 @@ def main():
         if world_size == 1 and args.cpu_spp > 0:
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)  # 16 = one GPU's CPU share
             out["cpu_baseline"] = cpu_baseline(args, threads)
+            out["host_loop"] = host_loop(args, threads)
         print(json.dumps(out), flush=True)
 
     ctx.close()

@@ -51,6 +51,7 @@ void *host_worker(void *p) {
         }
     }
     j->segments += seg; j->draws += drw; j->scans += scn;
+    if (std::getenv("MORT_HOST_DEBUG")) std::fprintf(stderr, "[host worker %lu] %llu segments\n", (unsigned long)pthread_self(), seg);
     return nullptr;
 }
 
