@@ -118,3 +118,92 @@ def test_grazing_hit_from_far_away_regression(monkeypatch):
     assert (tree["segments_px"][358] == scan["segments_px"][358]).all()
     assert (tree["accum"][358].view(np.uint32) == scan["accum"][358].view(np.uint32)).all()
     assert (tree["states"] == scan["states"]).all()
+
+
+def _random_world(rng, n_spheres, n_quads, n_boxes, n_media, with_light):
+    """A random brute-force world: spheres (some moving, some huge, some tiny), quads, rotated / translated boxes, media in
+    sphere boundaries; every material kind.  Returns (world, light (type, idx) or None)."""
+    import ctypes as C
+    L = host.lib()
+    w = host.World()
+
+    palette = []
+
+    def material():
+        # the reference's tables are small (20 isotropics, 50 dielectrics, ...): draw from a palette of at most 16
+        if len(palette) >= 16:
+            return palette[int(rng.integers(0, len(palette)))]
+        m = new_material()
+        palette.append(m)
+        return m
+
+    def new_material():
+        k = rng.integers(0, 6)
+        col = tuple(rng.uniform(0.1, 0.95, 3))
+        if k == 0:
+            return S.MAT_METAL, L.mort_add_metal(w.ptr, host.vec3(*col), float(rng.uniform(0, 1)))
+        if k == 1:
+            return S.MAT_DIELECTRIC, L.mort_add_dielectric(w.ptr, float(rng.uniform(1.1, 2.0)))
+        if k == 2:
+            c = L.mort_add_solid_color(w.ptr, host.vec3(*col))
+            return S.MAT_ISOTROPIC, L.mort_add_isotropic(w.ptr, S.TEXTURE_SOLID, c)
+        if k == 3:
+            c1 = L.mort_add_solid_color(w.ptr, host.vec3(*col)); c2 = L.mort_add_solid_color(w.ptr, host.vec3(.9, .9, .9))
+            ck = L.mort_add_checker_texture(w.ptr, float(rng.uniform(0.2, 2.0)), S.TEXTURE_SOLID, c1, S.TEXTURE_SOLID, c2)
+            return S.MAT_LAMBERTIAN, L.mort_add_lambertian(w.ptr, S.TEXTURE_CHECKER, ck)
+        c = L.mort_add_solid_color(w.ptr, host.vec3(*col))
+        return S.MAT_LAMBERTIAN, L.mort_add_lambertian(w.ptr, S.TEXTURE_SOLID, c)
+
+    light = None
+    if with_light:
+        c = L.mort_add_solid_color(w.ptr, host.vec3(7, 7, 7))
+        lm = L.mort_add_diffuse_light(w.ptr, S.TEXTURE_SOLID, c)
+        q = L.mort_add_quad(w.ptr, host.vec3(-2, 6, -2), host.vec3(4, 0, 0), host.vec3(0, 0, 4), S.MAT_DIFFUSE_LIGHT, lm, False)
+        light = (S.OBJ_QUAD, q)
+    mt, mi = material()
+    L.mort_add_sphere(w.ptr, host.vec3(0, -1000, 0), 1000.0, mt, mi, False)  # ground: a huge sphere among small ones
+    for _ in range(n_spheres):
+        mt, mi = material()
+        c = rng.uniform(-6, 6, 3) * (1, 0.3, 1) + (0, 1.2, 0)
+        r = float(rng.choice([0.05, 0.2, 0.5, 1.0, 1.5]))
+        if rng.random() < 0.3:
+            L.mort_add_moving_sphere(w.ptr, host.vec3(*c), host.vec3(*(c + rng.uniform(-0.5, 0.5, 3))), r, mt, mi, False)
+        else:
+            L.mort_add_sphere(w.ptr, host.vec3(*c), r, mt, mi, False)
+    for _ in range(n_quads):
+        mt, mi = material()
+        L.mort_add_quad(w.ptr, host.vec3(*rng.uniform(-5, 5, 3)), host.vec3(*rng.uniform(-2, 2, 3)), host.vec3(*rng.uniform(-2, 2, 3)), mt, mi, False)
+    for _ in range(n_boxes):
+        mt, mi = material()
+        L.mort_rotated_box(w.ptr, host.vec3(*rng.uniform(0.3, 2.0, 3)), host.vec3(*(rng.uniform(-5, 5, 3) * (1, 0, 1))), float(rng.uniform(-60, 60)), mt, mi)
+    for _ in range(n_media):
+        b = L.mort_add_sphere(w.ptr, host.vec3(*(rng.uniform(-4, 4, 3) * (1, 0.2, 1) + (0, 1, 0))), float(rng.uniform(0.5, 2.5)), S.MAT_DIELECTRIC, L.mort_add_dielectric(w.ptr, 1.5), True)
+        c = L.mort_add_solid_color(w.ptr, host.vec3(*rng.uniform(0.2, 1.0, 3)))
+        L.mort_add_constant_medium(w.ptr, S.OBJ_SPHERE, b, float(rng.uniform(0.05, 3.0)), S.MAT_ISOTROPIC, L.mort_add_isotropic(w.ptr, S.TEXTURE_SOLID, c), False)
+    w.c.bvh_mode = False
+    return w, light
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_unified_tree_equals_scan_on_random_worlds(oracle, seed):
+    """Random worlds x random cameras (inside, outside, far away, grazing the ground): the unified-tree walk, the
+    reference's scan (both in the product's host loop) and the oracle agree bit for bit."""
+    import ctypes as C
+    from tests.worlds import set_view
+    rng = np.random.default_rng(1000 + seed)
+    w, light = _random_world(rng, n_spheres=int(rng.integers(1, 60)), n_quads=int(rng.integers(0, 12)), n_boxes=int(rng.integers(0, 3)),
+                             n_media=int(rng.integers(0, 3)), with_light=bool(seed % 2))
+    _, cam = host.build_scene(2, width=56, spp=4, depth=int(rng.integers(2, 20)))
+    for i in range(3):
+        cam.background.e[i] = float(rng.uniform(0.0, 0.8)) * (0 if light and seed % 4 == 1 else 1)
+    if light:
+        cam.light_obj_type, cam.light_obj_idx = light
+    views = [((0, 2, 9), (0, 1, 0)), ((0.3, 0.05, 0.2), (4, 0.3, 1)), ((40, 25, -60), (0, 0, 0)), (tuple(rng.uniform(-5, 5, 3) + (0, 6, 0)), tuple(rng.uniform(-2, 2, 3)))]
+    for frm, at in views:
+        set_view(cam, frm, at, vfov=int(rng.integers(20, 90)), defocus=float(rng.choice([0.0, 0.0, 0.8])))
+        ref = oracle.render(w, cam, nthreads=8)
+        tree = hip.render_host(w, cam, nthreads=8, tree=True)
+        scan = hip.render_host(w, cam, nthreads=8, tree=False)
+        assert "unified tree" in tree["stats"]["kernel_name"]
+        same(tree, ref, oracle)
+        same(scan, ref, oracle)
