@@ -358,6 +358,140 @@ struct Compiler {
             else { const double st = x.a, ct = x.b, px = p[0], pz = p[2]; p[0] = ct * px + st * pz; p[2] = -st * px + ct * pz; }
         }
     }
+    /* ---- padded world boxes for this build's own trees (header of build_unified, steps 3 and 4): fills pr[i].wb.
+     * Spheres: a test that accepts root t_c puts P(t_c) at most 5 u M^2 / r outside the sphere, M = max(|oc|, r).  Rays
+     * whose origin is within 2R + 1 of the bounding sphere (G, R) of the ORDINARY spheres' centres are covered by the
+     * static pad; a ray from further away widens its own error band by kmin * (|o - G| + R)^2 (device: gen_ray_setup).
+     * GIANT spheres (radius above half the extent of all centres: a ground sphere, an enclosing shell) are left out of
+     * (G, R) -- their centres would blow it up -- and carry their distance D_i from it in their own static pad and in kmin. ---- */
+    struct PadInfo { Box all; float c[3]; float R, mnear, kmin, reach; bool ok; };
+    PadInfo pad_prims(std::vector<GPrim> &pr, bool with_boundaries) {
+        PadInfo pi;
+        std::memset(&pi, 0, sizeof pi);
+        pi.mnear = 1e30f;
+        /* pass 1: unpadded world boxes of the solids and of the media boundaries -> where ray origins can lie */
+        auto raw_box = [&](const GPrim &g, double pad_obj) {
+            Box b;
+            if (g.kind == ITEM_SPHERES) {
+                const DSphere &s = out.spheres[g.idx];
+                const float c0[3] = {s.cx, s.cy, s.cz}, c1[3] = {s.cx + s.vx, s.cy + s.vy, s.cz + s.vz};
+                const float r = std::fabs(s.radius);
+                for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(c0[k], c1[k]) - r; b.hi[k] = std::fmax(c0[k], c1[k]) + r; }
+            } else {
+                const DQuad &q = out.quads[g.idx];
+                for (int k = 0; k < 3; k++) {
+                    const float p0 = q.Q[k], p1 = q.Q[k] + q.u[k], p2 = q.Q[k] + q.v[k], p3 = q.Q[k] + q.u[k] + q.v[k];
+                    b.lo[k] = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3));
+                    b.hi[k] = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
+                }
+            }
+            double lo[3], hi[3];
+            for (int k = 0; k < 3; k++) { lo[k] = (double)b.lo[k] - pad_obj; hi[k] = (double)b.hi[k] + pad_obj; }
+            Box w;
+            for (int k = 0; k < 3; k++) { w.lo[k] = INFINITY; w.hi[k] = -INFINITY; }
+            for (int c = 0; c < 8; c++) {
+                double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+                chain_to_world(out.xforms, g.cf, g.cc, p);
+                for (int k = 0; k < 3; k++) {
+                    w.lo[k] = std::fmin(w.lo[k], std::nextafter((float)p[k], -INFINITY));
+                    w.hi[k] = std::fmax(w.hi[k], std::nextafter((float)p[k], INFINITY));
+                }
+            }
+            return w;
+        };
+        Box all;
+        for (int k = 0; k < 3; k++) { all.lo[k] = 0; all.hi[k] = 0; }
+        bool have_all = false;
+        auto grow = [&](const Box &w) {
+            for (int k = 0; k < 3; k++) if (!std::isfinite(w.lo[k]) || !std::isfinite(w.hi[k]) || std::fabs(w.lo[k]) > 1e15f || std::fabs(w.hi[k]) > 1e15f) return false;
+            all = have_all ? box_union(all, w) : w;
+            have_all = true;
+            return true;
+        };
+        for (const GPrim &g : pr) if (!grow(raw_box(g, 0.0))) return pi;
+        if (with_boundaries) for (const DItem &it : out.subitems) { /* a medium scatters inside its boundary */
+            if (it.kind != ITEM_SPHERES && it.kind != ITEM_QUADS) continue;
+            for (int i = it.first; i < it.first + it.count; i++) {
+                GPrim g; g.kind = it.kind; g.idx = i; g.cf = it.chain_first; g.cc = it.chain_count; g.chain_id = 0;
+                if (!grow(raw_box(g, 0.0))) return pi;
+            }
+        }
+        const double diag = have_all ? box_diag(all) : 1.0;
+        double amag = 0;
+        for (int k = 0; k < 3; k++) amag = std::fmax(amag, std::fmax(std::fabs((double)all.lo[k]), std::fabs((double)all.hi[k])));
+        /* origins: the camera centre (checked per render to lie within `reach` of the box) or a point in the box */
+        const double reach = 2.0 * diag + 4.0 * amag + 10.0;
+        const double Mq = amag + reach + diag + 1.0; /* bound on every coordinate the quad test and the ray transform see */
+        const double u = 5.9604644775390625e-08;
+        /* world-space centres (both ends of a moving sphere's path) and radii */
+        struct SC { double c0[3], c1[3], r; bool giant; double D; };
+        std::vector<SC> sc;
+        std::vector<size_t> sc_of(pr.size(), (size_t)-1);
+        for (size_t i = 0; i < pr.size(); i++) {
+            const GPrim &g = pr[i];
+            if (g.kind != ITEM_SPHERES) continue;
+            const DSphere &s = out.spheres[g.idx];
+            SC e;
+            for (int k = 0; k < 3; k++) { const double base[3] = {s.cx, s.cy, s.cz}, vel[3] = {s.vx, s.vy, s.vz}; e.c0[k] = base[k]; e.c1[k] = base[k] + vel[k]; }
+            chain_to_world(out.xforms, g.cf, g.cc, e.c0); chain_to_world(out.xforms, g.cf, g.cc, e.c1);
+            e.r = std::fabs((double)s.radius); e.giant = false; e.D = 0;
+            sc_of[i] = sc.size();
+            sc.push_back(e);
+        }
+        double G[3] = {0, 0, 0}, gR = 0, mnear = 1e30, kmin = 0;
+        if (!sc.empty()) {
+            auto centre_box = [&](bool skip_giants, double lo[3], double hi[3]) {
+                bool any = false;
+                for (const SC &e : sc) {
+                    if (skip_giants && e.giant) continue;
+                    for (int k = 0; k < 3; k++) {
+                        const double a0 = std::fmin(e.c0[k], e.c1[k]), a1 = std::fmax(e.c0[k], e.c1[k]);
+                        lo[k] = any ? std::fmin(lo[k], a0) : a0; hi[k] = any ? std::fmax(hi[k], a1) : a1;
+                    }
+                    any = true;
+                }
+                return any;
+            };
+            double lo[3], hi[3];
+            centre_box(false, lo, hi);
+            const double dall = std::sqrt((hi[0] - lo[0]) * (hi[0] - lo[0]) + (hi[1] - lo[1]) * (hi[1] - lo[1]) + (hi[2] - lo[2]) * (hi[2] - lo[2]));
+            size_t ngiant = 0;
+            for (SC &e : sc) { e.giant = sc.size() > 1 && e.r > 0.5 * dall; ngiant += e.giant ? 1 : 0; }
+            if (ngiant == sc.size()) for (SC &e : sc) e.giant = false; /* nothing ordinary to centre on: treat all alike */
+            centre_box(true, lo, hi);
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) { G[k] = 0.5 * (lo[k] + hi[k]); const double h = 0.5 * (hi[k] - lo[k]); d2 += h * h; }
+            gR = std::sqrt(d2) * 1.0001 + 1e-3 * (1.0 + amag); /* + the rounding of G and of the device's distance */
+            mnear = 3.0 * gR + 1.0;
+            for (SC &e : sc) {
+                double far2 = 0;
+                for (int end = 0; end < 2; end++) { double q = 0; for (int k = 0; k < 3; k++) { const double t = (end ? e.c1[k] : e.c0[k]) - G[k]; q += t * t; } far2 = std::fmax(far2, q); }
+                e.D = std::fmax(0.0, std::sqrt(far2) - gR);
+                const double ki = (e.r > 0) ? 20.0 * u * (1.0 + e.D / mnear) * (1.0 + e.D / mnear) / e.r : INFINITY;
+                kmin = std::fmax(kmin, ki);
+            }
+        }
+        for (int k = 0; k < 3; k++) pi.c[k] = (float)G[k];
+        pi.R = (float)gR; pi.mnear = (float)mnear; pi.kmin = std::nextafter((float)kmin, INFINITY);
+        for (GPrim &g : pr) {
+            double delta = 64.0 * u * Mq + 1e-4; /* quads; the rounding of ray_at and of the ray transform */
+            if (g.kind == ITEM_SPHERES) { /* near rays: |o - G| <= 2R + 1, so |oc| <= mnear + D_i; far rays widen their own band (kmin) */
+                const SC &e = sc[sc_of[(size_t)(&g - &pr[0])]];
+                const double M = std::fmax(e.r, mnear + e.D);
+                delta += (e.r > 0) ? 20.0 * u * M * M / e.r : INFINITY;
+            }
+            g.wb = box_pad(raw_box(g, delta));
+            for (int k = 0; k < 3; k++) {
+                g.wb.lo[k] -= (float)(64.0 * u * Mq); g.wb.hi[k] += (float)(64.0 * u * Mq);
+                if (!std::isfinite(g.wb.lo[k]) || !std::isfinite(g.wb.hi[k])) return pi;
+            }
+        }
+        pi.all = all;
+        pi.reach = (float)reach;
+        pi.ok = true;
+        return pi;
+    }
+
     uint32_t gen_emit(std::vector<GPrim> &pr, std::vector<int> &ids, int lo, int hi, int depth, Box &box_out) {
         const int n = hi - lo;
         Box u = pr[ids[lo]].wb;
@@ -436,98 +570,11 @@ struct Compiler {
         out.g_ranks.assign(out.spheres.size() + out.quads.size(), 0u);
         for (size_t i = 0; i < pr.size(); i++) /* pr is in scan order */
             out.g_ranks[(pr[i].kind == ITEM_QUADS ? out.spheres.size() : 0) + (size_t)pr[i].idx] = (uint32_t)i + 1u;
-        /* pass 1: unpadded world boxes of the solids and of the media boundaries -> where ray origins can lie */
-        auto raw_box = [&](const GPrim &g, double pad_obj) {
-            Box b;
-            if (g.kind == ITEM_SPHERES) {
-                const DSphere &s = out.spheres[g.idx];
-                const float c0[3] = {s.cx, s.cy, s.cz}, c1[3] = {s.cx + s.vx, s.cy + s.vy, s.cz + s.vz};
-                const float r = std::fabs(s.radius);
-                for (int k = 0; k < 3; k++) { b.lo[k] = std::fmin(c0[k], c1[k]) - r; b.hi[k] = std::fmax(c0[k], c1[k]) + r; }
-            } else {
-                const DQuad &q = out.quads[g.idx];
-                for (int k = 0; k < 3; k++) {
-                    const float p0 = q.Q[k], p1 = q.Q[k] + q.u[k], p2 = q.Q[k] + q.v[k], p3 = q.Q[k] + q.u[k] + q.v[k];
-                    b.lo[k] = std::fmin(std::fmin(p0, p1), std::fmin(p2, p3));
-                    b.hi[k] = std::fmax(std::fmax(p0, p1), std::fmax(p2, p3));
-                }
-            }
-            double lo[3], hi[3];
-            for (int k = 0; k < 3; k++) { lo[k] = (double)b.lo[k] - pad_obj; hi[k] = (double)b.hi[k] + pad_obj; }
-            Box w;
-            for (int k = 0; k < 3; k++) { w.lo[k] = INFINITY; w.hi[k] = -INFINITY; }
-            for (int c = 0; c < 8; c++) {
-                double p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
-                chain_to_world(out.xforms, g.cf, g.cc, p);
-                for (int k = 0; k < 3; k++) {
-                    w.lo[k] = std::fmin(w.lo[k], std::nextafter((float)p[k], -INFINITY));
-                    w.hi[k] = std::fmax(w.hi[k], std::nextafter((float)p[k], INFINITY));
-                }
-            }
-            return w;
-        };
-        Box all;
-        for (int k = 0; k < 3; k++) { all.lo[k] = 0; all.hi[k] = 0; }
-        bool have_all = false;
-        auto grow = [&](const Box &w) {
-            for (int k = 0; k < 3; k++) if (!std::isfinite(w.lo[k]) || !std::isfinite(w.hi[k]) || std::fabs(w.lo[k]) > 1e15f || std::fabs(w.hi[k]) > 1e15f) return false;
-            all = have_all ? box_union(all, w) : w;
-            have_all = true;
-            return true;
-        };
-        for (const GPrim &g : pr) if (!grow(raw_box(g, 0.0))) return;
-        for (const DItem &it : out.subitems) { /* a medium scatters inside its boundary */
-            if (it.kind != ITEM_SPHERES && it.kind != ITEM_QUADS) continue;
-            for (int i = it.first; i < it.first + it.count; i++) {
-                GPrim g; g.kind = it.kind; g.idx = i; g.cf = it.chain_first; g.cc = it.chain_count; g.chain_id = 0;
-                if (!grow(raw_box(g, 0.0))) return;
-            }
-        }
-        const double diag = have_all ? box_diag(all) : 1.0;
-        double amag = 0;
-        for (int k = 0; k < 3; k++) amag = std::fmax(amag, std::fmax(std::fabs((double)all.lo[k]), std::fabs((double)all.hi[k])));
-        /* origins: the camera centre (checked per render to lie within `reach` of the box) or a point in the box */
-        const double reach = 2.0 * diag + 4.0 * amag + 10.0;
-        const double Mq = amag + reach + diag + 1.0; /* bound on every coordinate the quad test and the ray transform see */
-        const double u = 5.9604644775390625e-08;
-        /* world-space bounding sphere (centre g_c, radius g_R) of all solid sphere centres, smallest radius */
-        double cl[3] = {1e300, 1e300, 1e300}, ch[3] = {-1e300, -1e300, -1e300}, rmin = 1e300;
-        bool have_sph = false;
-        for (const GPrim &g : pr) {
-            if (g.kind != ITEM_SPHERES) continue;
-            const DSphere &s = out.spheres[g.idx];
-            for (int e = 0; e < 2; e++) {
-                double p[3] = {(double)s.cx + e * (double)s.vx, (double)s.cy + e * (double)s.vy, (double)s.cz + e * (double)s.vz};
-                chain_to_world(out.xforms, g.cf, g.cc, p);
-                for (int k = 0; k < 3; k++) { cl[k] = std::fmin(cl[k], p[k]); ch[k] = std::fmax(ch[k], p[k]); }
-            }
-            rmin = std::fmin(rmin, std::fabs((double)s.radius));
-            have_sph = true;
-        }
-        double gR = 0, mnear = 1e30, kmin = 0;
-        if (have_sph) {
-            double d2 = 0;
-            for (int k = 0; k < 3; k++) { out.g_c[k] = (float)(0.5 * (cl[k] + ch[k])); const double h = 0.5 * (ch[k] - cl[k]); d2 += h * h; }
-            gR = std::sqrt(d2) * 1.0001 + 1e-3 * (1.0 + amag); /* + the rounding of g_c and of the device's distance */
-            mnear = 3.0 * gR + 1.0;
-            kmin = (rmin > 0) ? 20.0 * u / rmin : INFINITY;
-        }
-        out.g_R = (float)gR; out.g_mnear = (float)mnear; out.g_kmin = (float)kmin;
-        for (GPrim &g : pr) {
-            double delta = 64.0 * u * Mq + 1e-4; /* quads; the rounding of ray_at and of the ray transform */
-            if (g.kind == ITEM_SPHERES) { /* near rays: |oc| <= mnear; far rays widen their own band (g_kmin) */
-                const double r = std::fabs((double)out.spheres[g.idx].radius);
-                const double M = std::fmax(r, mnear);
-                delta += (r > 0) ? 20.0 * u * M * M / r : INFINITY;
-            }
-            g.wb = box_pad(raw_box(g, delta));
-            for (int k = 0; k < 3; k++) {
-                g.wb.lo[k] -= (float)(64.0 * u * Mq); g.wb.hi[k] += (float)(64.0 * u * Mq);
-                if (!std::isfinite(g.wb.lo[k]) || !std::isfinite(g.wb.hi[k])) return;
-            }
-        }
-        for (int k = 0; k < 3; k++) { out.g_lo[k] = all.lo[k]; out.g_hi[k] = all.hi[k]; }
-        out.g_reach = (float)reach;
+        const PadInfo pi = pad_prims(pr, true);
+        if (!pi.ok) return;
+        for (int k = 0; k < 3; k++) { out.g_lo[k] = pi.all.lo[k]; out.g_hi[k] = pi.all.hi[k]; out.g_c[k] = pi.c[k]; }
+        out.g_R = pi.R; out.g_mnear = pi.mnear; out.g_kmin = pi.kmin;
+        out.g_reach = pi.reach;
         if (!pr.empty()) {
             std::vector<int> ids(pr.size());
             for (size_t i = 0; i < pr.size(); i++) ids[i] = (int)i;

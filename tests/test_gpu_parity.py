@@ -242,40 +242,7 @@ def test_other_viewpoints(gpu_ctx, oracle, sid):
         assert_same(out, ref)
 
 
-def _custom_bvh_world(spheres, noise_seed=1):
-    """A world that is one BVH over the given spheres: (centre, radius, material) with material one of
-    ("lamb", rgb) ("checker",) ("noise",) ("image",) ("metal", rgb, fuzz) ("glass", ior) ("light", rgb) ("iso", rgb)."""
-    import ctypes as C
-    L = host.lib()
-    w = host.World()
-    lst = L.mort_add_hittable_list(w.ptr, True)
-    LAMB, METAL, DIEL, LIGHT, ISO = S.MAT_LAMBERTIAN, S.MAT_METAL, S.MAT_DIELECTRIC, S.MAT_DIFFUSE_LIGHT, S.MAT_ISOTROPIC
-    for centre, radius, mat in spheres:
-        kind = mat[0]
-        if kind in ("lamb", "light", "iso"):
-            col = L.mort_add_solid_color(w.ptr, host.vec3(*mat[1]))
-            add = {"lamb": L.mort_add_lambertian, "light": L.mort_add_diffuse_light, "iso": L.mort_add_isotropic}[kind]
-            mt, mi = {"lamb": LAMB, "light": LIGHT, "iso": ISO}[kind], add(w.ptr, S.TEXTURE_SOLID, col)
-        elif kind == "checker":
-            c1 = L.mort_add_solid_color(w.ptr, host.vec3(.2, .3, .1)); c2 = L.mort_add_solid_color(w.ptr, host.vec3(.9, .9, .9))
-            ck = L.mort_add_checker_texture(w.ptr, 0.32, S.TEXTURE_SOLID, c1, S.TEXTURE_SOLID, c2)
-            mt, mi = LAMB, L.mort_add_lambertian(w.ptr, S.TEXTURE_CHECKER, ck)
-        elif kind == "noise":
-            g = S.HostRng(); L.mort_host_rng_init(C.byref(g), noise_seed, 0)
-            nz = L.mort_add_noise_texture(w.ptr, 4.0, C.byref(g))
-            mt, mi = LAMB, L.mort_add_lambertian(w.ptr, S.TEXTURE_NOISE, nz)
-        elif kind == "image":
-            img = host.synthetic_earth(64, 32); w._keepalive.append(img)
-            im = L.mort_add_image_texture(w.ptr, img.ctypes.data, 64, 32)
-            mt, mi = LAMB, L.mort_add_lambertian(w.ptr, S.TEXTURE_IMAGE, im)
-        elif kind == "metal":
-            mt, mi = METAL, L.mort_add_metal(w.ptr, host.vec3(*mat[1]), mat[2])
-        else:
-            mt, mi = DIEL, L.mort_add_dielectric(w.ptr, mat[1])
-        L.mort_list_add(w.ptr, lst, S.OBJ_SPHERE, L.mort_add_sphere(w.ptr, host.vec3(*centre), radius, mt, mi, True))
-    L.mort_add_bvh(w.ptr, lst, False)
-    w.c.bvh_mode = True
-    return w
+from tests.worlds import custom_bvh_world as _custom_bvh_world, BVH_WORLDS
 
 
 @pytest.mark.parametrize("name", ["one", "two", "three", "coincident", "concentric_glass", "every_material"])
@@ -284,17 +251,7 @@ def test_small_and_awkward_bvh_worlds(gpu_ctx, oracle, name):
     nodes: generic kernel), the same sphere several times (equal t: ties -> reference walk), concentric glass shells,
     and every material / texture kind on a sphere (isotropic, emissive, checker, Perlin noise, image)."""
     import ctypes as C
-    ground = ((0, -100.5, -1), 100, ("checker",))
-    worlds = {
-        "one": [((0, 0, -1), 0.5, ("lamb", (.7, .3, .3)))],
-        "two": [ground, ((0, 0, -1), 0.5, ("glass", 1.5))],
-        "three": [ground, ((0, 0, -1), 0.5, ("lamb", (.1, .2, .5))), ((1, 0, -1), 0.5, ("metal", (.8, .6, .2), 0.3))],
-        "coincident": [ground] + [((0, 0, -1), 0.5, ("lamb", (.1 * k, .2, .5))) for k in range(5)] + [((0.3, 0, -1), 0.5, ("metal", (.8, .8, .8), 0.0))] * 3,
-        "concentric_glass": [ground, ((0, 0, -1), 0.5, ("glass", 1.5)), ((0, 0, -1), 0.4, ("glass", 1.0 / 1.5)), ((0, 0, -1), 0.2, ("glass", 1.5)),
-                             ((-1.1, 0, -1), 0.5, ("lamb", (.8, .8, 0))), ((1.1, 0, -1), 0.5, ("metal", (.8, .6, .2), 1.0))],
-        "every_material": [ground] + [((-3 + 1.0 * k, 0.0, -1.5 - 0.2 * k), 0.45, m) for k, m in enumerate(
-            [("lamb", (.7, .3, .3)), ("noise",), ("image",), ("metal", (.7, .6, .5), 0.2), ("glass", 1.5), ("light", (4, 4, 4)), ("iso", (.3, .6, .9))])],
-    }
+    worlds = BVH_WORLDS
     w = _custom_bvh_world(worlds[name])
     _, cam = host.build_scene(1, width=144, spp=9, depth=12)
     for i, v in enumerate((0.0, 0.6, 1.5)): cam.lookfrom.e[i] = v
