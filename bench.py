@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MODE_NAMES = {"mega": "megakernel", "wave": "wavefront kernels", "throughput": "megakernel over (pixel, stratum row) streams [non-parity]"}
 SCENE_NAMES = {1: "random-spheres cover", 2: "two checker spheres", 3: "earth", 4: "two Perlin spheres", 5: "quads",
                6: "Cornell box, emissive light + MIS", 7: "Cornell smoke", 8: "book-2 final scene", 9: "book-2 final scene, low settings",
                10: "out-of-order spheres"}
@@ -101,7 +102,8 @@ def profile_figures(tag, kernel_substr):
     try:
         c = {}
         for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_pmc_sq_summary.csv"))):
-            if kernel_substr in r["kernel"] and "true" not in r["kernel"].split("<")[-1].split()[1:2]:
+            targs = [t.strip() for t in r["kernel"].split("<")[-1].split(">")[0].split(",")]  # mega_bvh_kernel<BLOCK, PROBE, DRAIN, SUB>
+            if kernel_substr in r["kernel"] and "true" not in targs[1:2] + targs[3:4]:  # neither the cost probe nor the non-parity launch
                 c.setdefault(r["counter"], float(r.get("max_dispatch") or r["per_dispatch"]))
         # 1024 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines; a VALU instruction holds its SIMD for 4 cycles
         out["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0)
@@ -129,8 +131,10 @@ def main():
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")
     ap.add_argument("--cpu-width", type=int, default=0, help="image width of the CPU-baseline sample (0 = the benchmarked width; 160 for scenes 8/9)")
-    ap.add_argument("--mode", choices=["mega", "wave"], default="mega",
-                    help="mega: the headline megakernel; wave: the wavefront (HBM-streaming) form of the same path")
+    ap.add_argument("--mode", choices=["mega", "wave", "throughput"], default="mega",
+                    help="mega: the headline megakernel; wave: the wavefront (HBM-streaming) form of the same path; throughput: the labelled "
+                         "NON-PARITY mode (one stream per (pixel, stratum row) -- other random numbers than the reference's; never the headline)")
+    ap.add_argument("--no-throughput-line", action="store_true", help="skip the extra non-parity figure (profiling runs: keeps the kernel list to the headline's)")
     args = ap.parse_args()
 
     import torch
@@ -171,9 +175,9 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     ev_pairs = []
-    mode = hip.MODE_WAVE if args.mode == "wave" else hip.MODE_MEGA
+    mode = {"wave": hip.MODE_WAVE, "throughput": hip.MODE_THROUGHPUT}.get(args.mode, hip.MODE_MEGA)
 
-    def step(record):
+    def step(record, mode=mode):
         e0 = e1 = None
         if record:
             e0 = torch.cuda.Event(enable_timing=True)
@@ -204,10 +208,22 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = [a.elapsed_time(b) for a, b in ev_pairs]
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    # the labelled non-parity mode, timed the same way beside the headline (BVH-of-spheres worlds only); never `value`
+    elapsed_tp = None
+    if args.mode == "mega" and args.scene in (1, 10) and not args.no_throughput_line:
+        step(False, hip.MODE_THROUGHPUT)  # seeds the sub-streams
+        step(False, hip.MODE_THROUGHPUT)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(False, hip.MODE_THROUGHPUT)
+        sync_all()
+        elapsed_tp = time.perf_counter() - t1
+    t = torch.tensor([elapsed, elapsed_tp or 0.0], dtype=torch.float64, device=dev)
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed_max = float(t.item())
+    elapsed_max = float(t[0].item())
+    elapsed_tp = float(t[1].item()) if elapsed_tp is not None else None
 
     # one more frame through the blocking entry to read the library's own counters/HIP-event time
     st = ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, mode=mode, sync=True)
@@ -218,6 +234,8 @@ def main():
         avg_kernel_s = (sum(kernel_ms) / max(len(kernel_ms), 1)) * 1e-3
         pixels_launch = W * lr
         algo_bytes = 100 * pixels_launch  # 48 B state in + 48 B out + 4 B uchar4 per pixel; 0 B per segment
+        if args.mode == "throughput":  # per (pixel, stratum row): 48 B state in + 48 B out + 12 B partial sum; the resolve kernel's 12 B in and 4 B per pixel out
+            algo_bytes = pixels_launch * (cam.sqrt_spp * (96 + 12 + 12) + 4)
         if args.mode == "wave":
             algo_bytes = int(st["algorithmic_hbm_bytes"])  # + 240 B per segment of front / hit / pixel / stack records (wave_bvh.h)
         achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
@@ -230,12 +248,13 @@ def main():
             pf = {"traffic": None}
         traffic = pf.get("traffic")
         out = {
-            "metric": f"Msamples/sec (width x height x spp/s), Scene {args.scene} {W}x{H}",
+            "metric": f"Msamples/sec (width x height x spp/s), Scene {args.scene} {W}x{H}" +
+                      (" -- NON-PARITY throughput mode (own RNG streams; not the reference's image)" if args.mode == "throughput" else ""),
             "value": value, "unit": "Msamples/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"Scene {args.scene} ({SCENE_NAMES.get(args.scene, '?')}) {W}x{H}, {args.spp} spp nominal = {eff} effective, "
-                                   f"depth {cam.bounce_limit}, {'megakernel' if args.mode == 'mega' else 'wavefront kernels'}, seed 69420, host LCG scene",
+                                   f"depth {cam.bounce_limit}, {MODE_NAMES[args.mode]}, seed 69420, host LCG scene",
                        "mode": args.mode, "partition": f"rows/{args.rows_per_block} interleaved over {world_size} rank(s)",
                        "nominal_msamples_per_s": W * H * args.spp * args.steps / elapsed_max / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -246,6 +265,8 @@ def main():
                          "traffic_source": pf.get("traffic_source"),
                          "note": ("megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
                                   "so the HBM fraction is tiny; the binding resource is VALU issue (DESIGN.md 4)") if args.mode == "mega" else
+                                 ("NON-PARITY mode: one stream per (pixel, stratum row), so a pixel's sqrt_spp rows are independent work items; results are "
+                                  "this mode's own (tests/test_gpu_throughput.py), not the reference's -- reported beside the headline, never as it") if args.mode == "throughput" else
                                  ("wavefront form: 100 B per pixel + 240 B per segment of front / hit / pixel / stack records; bound by "
                                   "front granularity (one segment of every live pixel per launch pair), not by HBM (DESIGN.md 4)"),
                          "valu_issue_frac": pf.get("valu_issue_frac"), "valu_lane_occupancy": pf.get("valu_lane_occupancy"),
@@ -253,6 +274,11 @@ def main():
             "kernel": {"segments_per_frame": st["segments"], "segments_per_s": st["segments"] / st["seconds"],
                        "hip_event_seconds": st["seconds"], "vgprs": st["kernel_vgprs"], "lds_bytes": st["kernel_lds_bytes"]},
         }
+        if elapsed_tp:
+            out["nonparity_throughput_mode"] = {
+                "value": samples_per_step * args.steps / elapsed_tp / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed_tp / args.steps * 1e3,
+                "note": "MORT_MODE_THROUGHPUT: one XORWOW stream per (pixel, stratum row) instead of the reference's one per pixel -- same estimator and "
+                        "per-sample arithmetic, other random numbers, so NOT the reference's image; an extra figure, not the headline (DESIGN.md 4.8)"}
         if world_size == 1 and args.cpu_spp > 0:
             threads = args.cpu_threads or min(len(os.sched_getaffinity(0)), 16)  # 16 = one GPU's CPU share
             out["cpu_baseline"] = cpu_baseline(args, threads)

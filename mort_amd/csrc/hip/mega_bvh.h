@@ -63,6 +63,10 @@ struct FastArgs {
     unsigned *tile_cost;        /* per tile: segments traced this frame (feeds the next frame's order), or null */
     int th_s, th_l, t_keep; /* scheduling thresholds (lanes): batch sizes that trigger a shade / leaf step, and the
                                lane count below which the box-step loop hands control back (wave-uniform) */
+    /* MORT_MODE_THROUGHPUT (NOT the reference's streams): one stream and one work item per (pixel, stratum row).  The launch then
+     * covers a VIRTUAL image of local_rows * sub rows: virtual row = row * sub + s_j; r.states / vaccum are indexed by virtual pixel */
+    int sub;                    /* 0, or sqrt_spp in sub-stream launches */
+    float *vaccum;              /* sub-stream launches: per virtual pixel, the unscaled colour sum of its stratum row (3 floats) */
 };
 
 enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
@@ -195,11 +199,22 @@ enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 
 /* ---- a pixel's end and the next pixel's start: once per 484 samples per lane, kept out of line so that their
  * registers and code stay out of the shade step (like the texture and reference-walk paths above) ---- */
-template <bool PROBE>
+template <bool PROBE, bool SUB = false>
 __device__ __attribute__((noinline)) void pixel_write(const FastArgs *fap, float sx, float sy, float sz, int lofs, uint32_t segments,
                                                       uint32_t draws, uint32_t d, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4) {
     const FastArgs &fa = *fap;
     const RenderArgs &a = fa.r;
+    if (SUB) { /* a stratum row of a pixel: its colour sum goes to the virtual accumulator, the resolve kernel finishes the pixel */
+        fa.vaccum[3 * (size_t)lofs] = sx; fa.vaccum[3 * (size_t)lofs + 1] = sy; fa.vaccum[3 * (size_t)lofs + 2] = sz;
+        mort_rng_state st;
+        st.d = d; st.v[0] = v0; st.v[1] = v1; st.v[2] = v2; st.v[3] = v3; st.v[4] = v4;
+        st.boxmuller_flag = 0; st.boxmuller_flag_double = 0; st.boxmuller_extra = 0.f; st.boxmuller_extra_double = 0.;
+        a.states[lofs] = st;
+        const unsigned slot = 32u + 2u * (blockIdx.x & 31u);
+        atomicAdd(&a.counters[slot], (unsigned long long)segments);
+        atomicAdd(&a.counters[slot + 1u], (unsigned long long)draws);
+        return;
+    }
     V3 c = vscale(a.pixel_samples_scale, mk(sx, sy, sz)); /* camera.cuh:194-207 */
     if (c.x != c.x) c.x = 0.0f;
     if (c.y != c.y) c.y = 0.0f;
@@ -232,12 +247,14 @@ __device__ __attribute__((noinline)) void pixel_write(const FastArgs *fap, float
         atomicAdd(&a.counters[slot + 1u], (unsigned long long)draws);
     }
 }
-struct PixelFetch { int got; int xy, lofs; uint32_t d, v0, v1, v2, v3, v4; };
+struct PixelFetch { int got; /* 0, or 1 + the stratum row (SUB) */ int xy, lofs; uint32_t d, v0, v1, v2, v3, v4; };
 /* one atomicAdd per wave per refill; the lanes that call this together take consecutive slots */
+template <bool SUB = false>
 __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap, unsigned total_q) {
     const FastArgs &fa = *fap;
     const RenderArgs &a = fa.r;
     PixelFetch pf; pf.got = 0; pf.xy = 0; pf.lofs = 0; pf.d = pf.v0 = pf.v1 = pf.v2 = pf.v3 = pf.v4 = 0;
+    const int vrows = SUB ? a.local_rows * fa.sub : a.local_rows; /* rows of the (virtual) image the tiles cover */
     bool done = false;
     while (!done) {
         const unsigned long long need = __ballot(1);
@@ -267,10 +284,11 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
         const int tile = fa.tile_order ? (int)fa.tile_order[tslot] : tslot;
         const int tx = tile % fa.tiles_x, ty = tile / fa.tiles_x;
         const int qx = tx * 8 + (within & 7), qly = ty * 8 + (within >> 3);
-        if (qx < a.width && qly < a.local_rows) {
-            pf.xy = qx | (global_row(qly, a.rank, a.nranks, a.rows_per_block) << 16);
+        if (qx < a.width && qly < vrows) {
+            const int rly = SUB ? qly / fa.sub : qly; /* the pixel's local row; SUB: qly = row * sub + stratum row */
+            pf.xy = qx | (global_row(rly, a.rank, a.nranks, a.rows_per_block) << 16);
             pf.lofs = qx + qly * a.width;
-            pf.got = 1;
+            pf.got = SUB ? 1 + (qly - rly * fa.sub) : 1;
             done = true;
         }
     }
@@ -283,7 +301,10 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
 
 /* PROBE = true is the 1-sample cost probe (its own symbol, so profiles keep the frame kernel's durations apart) */
 /* DRAIN = true adds the drain mode below (chain-bound partitions; it costs the throughput-bound frame 5 % in registers) */
-template <int BLOCK, bool PROBE, bool DRAIN = false>
+/* SUB = true: MORT_MODE_THROUGHPUT's launch over (pixel, stratum row) work items with their own streams (FastArgs.sub) -- labelled, never parity.
+ * (A thin wrapper kernel around a shared body would keep the three-parameter symbol names, but it perturbs the frame kernel's register
+ * allocation: 136 instead of 122 scratch instructions) */
+template <int BLOCK, bool PROBE, bool DRAIN = false, bool SUB = false>
 __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const RenderArgs &a = fa.r;
@@ -579,25 +600,31 @@ __global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const F
                     ident_mask = 0ull;
                     pixel_color = vadd(pixel_color, final_value);
                     s_ij++;
-                    if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
-                    if ((s_ij >> 16) < a.sqrt_spp) {
+                    bool more; /* samples left in this work item (SUB: one stratum row) */
+                    if constexpr (SUB) {
+                        more = (s_ij & 0xffff) != a.sqrt_spp;
+                    } else {
+                        if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
+                        more = (s_ij >> 16) < a.sqrt_spp;
+                    }
+                    if (more) {
                         kind = K_NEWSAMPLE;
                     } else {
-                        pixel_write<PROBE>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        pixel_write<PROBE, SUB>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
                         kind = K_NEWPIX;
                     }
                 }
                 REGION("S:newpix");
                 PROFS(5);
                 if (kind == K_NEWPIX) {
-                    const PixelFetch pf = pixel_fetch(&fa, total_q);
+                    const PixelFetch pf = pixel_fetch<SUB>(&fa, total_q);
                     if (!pf.got) state = ST_DONE;
                     else {
                         xy = pf.xy; lofs = pf.lofs;
                         rng.d = pf.d; rng.v0 = pf.v0; rng.v1 = pf.v1; rng.v2 = pf.v2; rng.v3 = pf.v3; rng.v4 = pf.v4;
                         rng.draws = 0;
                         pixel_color = mk(0, 0, 0);
-                        s_ij = 0; segments = 0;
+                        s_ij = SUB ? ((pf.got - 1) << 16) : 0; segments = 0;
                         kind = (spp > 0) ? K_NEWSAMPLE : K_FINISH;
                         if (spp <= 0) { /* degenerate: zero samples -> 0 * inf = NaN -> 0 */
                             final_value = mk(0, 0, 0);

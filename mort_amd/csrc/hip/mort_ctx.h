@@ -30,6 +30,13 @@ struct mort_ctx {
     mort_rng_state *d_states = nullptr;
     int rng_w = 0, rng_h = 0, rng_local_rows = 0;
     uint32_t *d_seqmats = nullptr;
+    /* MORT_MODE_THROUGHPUT: one stream per (pixel, stratum row), seeded on first use from the seed of mort_hip_rng_seed */
+    uint64_t seed = 0;
+    bool seed_known = false; /* false after rng_load: those states have no seed to derive sub-streams from */
+    mort_rng_state *d_substates = nullptr;
+    float *d_vaccum = nullptr;
+    size_t substates_cap = 0, vaccum_cap = 0;
+    int sub_w = 0, sub_h = 0, sub_lr = 0, sub_s = 0; /* what d_substates is seeded for (0 = nothing) */
     /* scratch */
     void *d_rgba = nullptr, *d_accum = nullptr, *d_segpx = nullptr;
     size_t rgba_cap = 0, accum_cap = 0, segpx_cap = 0;

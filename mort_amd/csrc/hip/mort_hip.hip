@@ -64,16 +64,19 @@ struct SeedArgs {
     int levels;
     int width, local_rows, rank, nranks, rows_per_block;
     uint32_t d0, v0, v1, v2, v3, v4; /* scrambled seed */
+    int sub; /* 0: the reference's keying, subsequence x + y*W.  S > 0 (MORT_MODE_THROUGHPUT): states[x + (ly*S + j)*W] gets subsequence x + (y*S + j)*W */
 };
 
 extern "C" __global__ void __launch_bounds__(256)
 seed_kernel(const SeedArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = a.width * a.local_rows;
+    const int sub = a.sub > 0 ? a.sub : 1;
+    const long long n = (long long)a.width * a.local_rows * sub;
     if (i >= n) return;
-    const int ly = i / a.width, x = i - ly * a.width;
+    const int vly = i / a.width, x = i - vly * a.width;
+    const int ly = vly / sub, j = vly - ly * sub;
     const int y = global_row(ly, a.rank, a.nranks, a.rows_per_block);
-    unsigned long long p = (unsigned long long)x + (unsigned long long)y * (unsigned long long)a.width;
+    unsigned long long p = (unsigned long long)x + ((unsigned long long)y * (unsigned long long)sub + (unsigned long long)j) * (unsigned long long)a.width;
     uint32_t v[5] = {a.v0, a.v1, a.v2, a.v3, a.v4};
     for (int k = 0; p != 0 && k < a.levels; k++, p >>= 2) {
         const uint32_t *m = a.mats + (size_t)k * 160 * 5;
@@ -99,6 +102,35 @@ seed_kernel(const SeedArgs a) {
 
 #include "mega_bvh.h"
 #include "wave_bvh.h"
+
+/* finishes the pixels of a sub-stream launch: stratum rows summed in order, then Camera::render's tail (camera.cuh:194-207) */
+static __global__ void __launch_bounds__(256) substream_resolve_kernel(const float *vaccum, int width, int local_rows, int sub, float scale, uchar4 *rgba, float *accum) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= width * local_rows) return;
+    const int ly = i / width, x = i - ly * width;
+    V3 c = mk(0, 0, 0);
+    for (int j = 0; j < sub; j++) {
+        const size_t v = 3 * ((size_t)(ly * sub + j) * (size_t)width + (size_t)x);
+        c = vadd(c, mk(vaccum[v], vaccum[v + 1], vaccum[v + 2]));
+    }
+    c = vscale(scale, c);
+    if (c.x != c.x) c.x = 0.0f;
+    if (c.y != c.y) c.y = 0.0f;
+    if (c.z != c.z) c.z = 0.0f;
+    if (accum) { accum[3 * i] = c.x; accum[3 * i + 1] = c.y; accum[3 * i + 2] = c.z; }
+    float g[3] = {mort_sqrtf(c.x), mort_sqrtf(c.y), mort_sqrtf(c.z)};
+    unsigned char b[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float v = g[k];
+        if (v < 0.0f) v = 0.0f;
+        if (v > 0.999f) v = 0.999f;
+        b[k] = (unsigned char)mort_f2i(256 * v);
+    }
+    uchar4 out; out.x = b[0]; out.y = b[1]; out.z = b[2]; out.w = 255;
+    rgba[i] = out;
+}
+
 
 /* ====================================================================== host */
 
@@ -178,6 +210,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     mort_hip_comm_destroy(c);
     hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
     hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
+    hipFree(c->d_substates); hipFree(c->d_vaccum);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
     hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states);
     if (c->h_live) hipHostFree(c->h_live);
@@ -197,6 +230,7 @@ extern "C" int mort_hip_set_partition(mort_ctx *c, const mort_partition *p) {
     c->cost_key = 0;
     /* RNG states are laid out per partition: force a re-seed */
     c->rng_w = c->rng_h = c->rng_local_rows = 0;
+    c->sub_w = c->sub_h = c->sub_lr = c->sub_s = 0;
     return MORT_OK;
 }
 
@@ -311,6 +345,9 @@ extern "C" int mort_hip_rng_seed(mort_ctx *c, uint64_t seed, int width, int heig
     a.rank = c->part.rank; a.nranks = c->part.nranks; a.rows_per_block = c->part.rows_per_block;
     const SeedWords sw = seed_scramble(seed);
     a.d0 = sw.d; a.v0 = sw.v[0]; a.v1 = sw.v[1]; a.v2 = sw.v[2]; a.v3 = sw.v[3]; a.v4 = sw.v[4];
+    a.sub = 0;
+    c->seed = seed; c->seed_known = true;
+    c->sub_w = c->sub_h = c->sub_lr = c->sub_s = 0; /* a re-seed restarts the sub-streams too */
     const int n = width * c->rng_local_rows;
     if (n > 0) {
         hipLaunchKernelGGL(seed_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, a);
@@ -326,6 +363,8 @@ extern "C" int mort_hip_rng_load(mort_ctx *c, const mort_rng_state *states, int 
     HIPCHK(c, quiesce(c));
     int st = ensure_states(c, width, height);
     if (st != MORT_OK) return st;
+    c->seed_known = false;
+    c->sub_w = c->sub_h = c->sub_lr = c->sub_s = 0;
     for (int ly = 0; ly < c->rng_local_rows; ly++) {
         const int y = global_row_host(c->part, ly);
         HIPCHK(c, hipMemcpy(c->d_states + (size_t)ly * width, states + (size_t)y * width, (size_t)width * sizeof(mort_rng_state), hipMemcpyHostToDevice));
@@ -493,13 +532,47 @@ static int prepare_tile_order(mort_ctx *c, const mort_camera *cam, const RenderA
     return MORT_OK;
 }
 
+/* MORT_MODE_THROUGHPUT: the (pixel, stratum row) streams for this image, partition and sqrt_spp; seeded once, then carried from
+ * frame to frame like the per-pixel states */
+static int ensure_substates(mort_ctx *c, int W, int H, int S, hipStream_t s) {
+    const int lr = c->rng_local_rows;
+    const size_t n = (size_t)W * (size_t)lr * (size_t)S;
+    if (n >= (1ull << 31)) return MORT_ERR_CAPACITY;
+    if (c->substates_cap < n) {
+        if (c->d_substates) { hipFree(c->d_substates); c->d_substates = nullptr; }
+        c->substates_cap = 0; c->sub_s = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_substates, (n ? n : 1) * sizeof(mort_rng_state)));
+        c->substates_cap = n;
+    }
+    if (c->vaccum_cap < n) {
+        if (c->d_vaccum) { hipFree(c->d_vaccum); c->d_vaccum = nullptr; }
+        c->vaccum_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_vaccum, (n ? n : 1) * 3 * sizeof(float)));
+        c->vaccum_cap = n;
+    }
+    if (c->sub_w == W && c->sub_h == H && c->sub_lr == lr && c->sub_s == S) return MORT_OK;
+    SeedArgs a;
+    a.states = c->d_substates; a.mats = c->d_seqmats; a.levels = SEQ_LEVELS;
+    a.width = W; a.local_rows = lr;
+    a.rank = c->part.rank; a.nranks = c->part.nranks; a.rows_per_block = c->part.rows_per_block;
+    const SeedWords sw = seed_scramble(c->seed);
+    a.d0 = sw.d; a.v0 = sw.v[0]; a.v1 = sw.v[1]; a.v2 = sw.v[2]; a.v3 = sw.v[3]; a.v4 = sw.v[4];
+    a.sub = S;
+    if (n > 0) {
+        hipLaunchKernelGGL(seed_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+        HIPCHK(c, hipGetLastError());
+    }
+    c->sub_w = W; c->sub_h = H; c->sub_lr = lr; c->sub_s = S;
+    return MORT_OK;
+}
+
 /* d_segpx: per-pixel segment counts for the packed owned rows, or null.  Only mort_hip_render passes one (sized for
  * THIS image and partition); the public device entry never does, so a buffer left over from an earlier, smaller
  * render can not be written past its end. */
 static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum, uint32_t *d_segpx,
                               void *stream, mort_stats *stats) {
     if (!c || !cam || !d_rgba) return MORT_ERR_INVALID;
-    if (mode != MORT_MODE_MEGA && mode != MORT_MODE_WAVE) return MORT_ERR_INVALID;
+    if (mode != MORT_MODE_MEGA && mode != MORT_MODE_WAVE && mode != MORT_MODE_THROUGHPUT) return MORT_ERR_INVALID;
     if (!c->have_world) return MORT_ERR_NO_WORLD;
     const int W = cam->image_width, H = cam->image_height;
     if (W <= 0 || H <= 0 || cam->sqrt_spp < 0) return MORT_ERR_INVALID;
@@ -526,7 +599,9 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
     { const char *dp = std::getenv("MORT_DEBUG_PIXEL"); if (dp) a.debug_lofs = std::atoi(dp); }
 
     HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s));
-    const int tiles = ((W + 7) / 8) * ((a.local_rows + 7) / 8);
+    /* MORT_MODE_THROUGHPUT: the launch covers a virtual image of local_rows * sqrt_spp rows (mega_bvh.h FastArgs.sub) */
+    const bool substream = mode == MORT_MODE_THROUGHPUT;
+    const int tiles = ((W + 7) / 8) * (((substream ? a.local_rows * (cam->sqrt_spp > 0 ? cam->sqrt_spp : 1) : a.local_rows) + 7) / 8);
     const int waves_per_block = 4;
     const int blocks = (tiles + waves_per_block - 1) / waves_per_block;
     const char *force = std::getenv("MORT_FORCE_GENERIC");
@@ -572,6 +647,13 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             if (!wave_gen) return MORT_ERR_UNSUPPORTED;
         }
     }
+    if (substream) {
+        if (!use_fast || d_segpx) return MORT_ERR_UNSUPPORTED;
+        if (!c->seed_known) return MORT_ERR_NO_RNG;
+        if ((long long)a.local_rows * cam->sqrt_spp >= 32768ll * 64) return MORT_ERR_CAPACITY;
+        int st_s = ensure_substates(c, W, H, cam->sqrt_spp, s);
+        if (st_s != MORT_OK) return st_s;
+    }
     if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
     if (blocks > 0 && mode == MORT_MODE_WAVE && wave_gen) {
         GenArgs ga = c->gen;
@@ -603,6 +685,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         fa.node_first = 0; fa.node_count = c->sc.n_nodes; /* the reference's threaded nodes (HBM): fallback walk */
         fa.next_q = (unsigned int *)(c->d_counters + 2);
         fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
+        if (substream) { fa.sub = cam->sqrt_spp; fa.vaccum = c->d_vaccum; fa.r.states = c->d_substates; }
         const long long lanes_wanted = (long long)tiles * 64;
         const double px_per_lane = (double)lanes_wanted / ((double)c->num_cus * 768.0);
         /* workgroup size: the largest of {768, 512, 384, 256} that still gives every CU a workgroup
@@ -617,14 +700,17 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         }
         void (*kern)(const FastArgs) = nullptr, (*kern_probe)(const FastArgs) = nullptr;
         /* chain-bound partition (about one pixel per lane or fewer): drain mode + spread fetches (mega_bvh.h) */
-        bool chain_bound = px_per_lane < 1.5;
-        { const char *cb = std::getenv("MORT_CHAIN_BOUND"); if (cb) chain_bound = cb[0] == '1'; }
+        bool chain_bound = px_per_lane < 1.5 && !substream;
+        { const char *cb = std::getenv("MORT_CHAIN_BOUND"); if (cb && !substream) chain_bound = cb[0] == '1'; }
         switch (FB) {
         case 768: kern = chain_bound ? mega_bvh_kernel<768, false, true> : mega_bvh_kernel<768, false, false>; kern_probe = mega_bvh_kernel<768, true, false>; break;
         case 512: kern = chain_bound ? mega_bvh_kernel<512, false, true> : mega_bvh_kernel<512, false, false>; kern_probe = mega_bvh_kernel<512, true, false>; break;
         case 384: kern = chain_bound ? mega_bvh_kernel<384, false, true> : mega_bvh_kernel<384, false, false>; kern_probe = mega_bvh_kernel<384, true, false>; break;
         default: FB = 256; kern = chain_bound ? mega_bvh_kernel<256, false, true> : mega_bvh_kernel<256, false, false>; kern_probe = mega_bvh_kernel<256, true, false>; break;
         }
+        if (substream) /* <BLOCK, PROBE, DRAIN, SUB> */
+            kern = FB == 768 ? mega_bvh_kernel<768, false, false, true> : FB == 512 ? mega_bvh_kernel<512, false, false, true>
+                   : FB == 384 ? mega_bvh_kernel<384, false, false, true> : mega_bvh_kernel<256, false, false, true>;
         /* scheduling thresholds (mega_bvh.h).  Smaller batches do not help a chain-bound partition: measured on
          * one rank of 8, (32,24,16) 100 ms, (12,12,8) 126 ms, (2,2,2) 192 ms -- a lane waits through every step
          * its wave runs for other lanes, and small batches mean more of those */
@@ -652,9 +738,9 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         if (grid < 1) grid = 1;
         lds_bytes_used = (int)lds_bytes;
         fast_kernel_used = (const void *)kern;
-        std::snprintf(kname, sizeof kname, "mega_bvh_kernel<%d, false, %s>", FB, chain_bound ? "true" : "false");
-        /* ---- tile order: expensive tiles first ---- */
-        if (!std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
+        std::snprintf(kname, sizeof kname, "mega_bvh_kernel<%d, false, %s, %s>", FB, chain_bound ? "true" : "false", substream ? "true" : "false");
+        /* ---- tile order: expensive tiles first (sub-stream launches: work items are a stratum row, 1/sqrt_spp of a pixel -- no long tail to order away) ---- */
+        if (!substream && !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
             int st_o = prepare_tile_order(c, cam, a, fa, tiles, grid, FB, chain_bound, s, [&](const FastArgs &pa) {
                 hipError_t e_ = hipFuncSetAttribute((const void *)kern_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
                 if (e_ != hipSuccess) return e_;
@@ -666,6 +752,12 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(FB), lds_bytes, s, fa);
         HIPCHK(c, hipGetLastError());
+        if (substream) {
+            const int npx = W * a.local_rows;
+            hipLaunchKernelGGL(substream_resolve_kernel, dim3((npx + 255) / 256), dim3(256), 0, s, (const float *)c->d_vaccum, W, a.local_rows, cam->sqrt_spp,
+                               a.pixel_samples_scale, (uchar4 *)d_rgba, (float *)d_accum);
+            HIPCHK(c, hipGetLastError());
+        }
     } else if (blocks > 0 && use_gen) {
         GenArgs ga;
         std::memset(&ga, 0, sizeof ga);

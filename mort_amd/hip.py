@@ -19,6 +19,7 @@ _lib = None
 
 MODE_MEGA = 0
 MODE_WAVE = 1
+MODE_THROUGHPUT = 2  # non-parity: one stream per (pixel, stratum row); see include/mort_hip.h
 
 EXPORTS = [
     "mort_hip_strerror", "mort_hip_last_error", "mort_hip_init", "mort_hip_shutdown", "mort_hip_upload_world",
