@@ -5,7 +5,7 @@
  * (include/book.h:21-30).
  *
  *   mort <scene_id> [--width W] [--aspect A] [--spp N] [--depth D] [--seed S] [--frames N]
- *                   [--mode mega|wave|host] [--threads T] [--tree]       host: the kernel body as a host loop (no GPU)
+ *                   [--mode mega|wave|host|throughput] [--threads T] [--tree]       host: the kernel body as a host loop (no GPU)
  *                   [--gpus N] [--devices a,b,..] [--gather rccl|shm]     one process per GPU, rows partitioned, one gather
  *                   [--out f.ppm] [--dump-f32 f.raw] [--states-in f] [--states-out f] [--earth img] [--rtl] [--device K]
  *                   [--keys WASD..] [--mouse dx,dy]        the reference's interactive loop, scripted: one idle tick per frame
@@ -39,7 +39,7 @@ static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &
 
 static int usage(void) {
     printf("Usage: mort <number_between_1_and_10> [--width W] [--aspect A] [--spp N] [--depth D] [--seed S] [--frames N] "
-           "[--mode mega|wave|host] [--threads T] [--tree] [--gpus N] [--devices a,b,..] [--gather rccl|shm] "
+           "[--mode mega|wave|host|throughput] [--threads T] [--tree] [--gpus N] [--devices a,b,..] [--gather rccl|shm] "
            "[--out f.ppm] [--dump-f32 f.raw] [--states-in f] [--states-out f] [--earth image.jpg|.ppm] [--rtl] [--device K] [--keys WASD..] [--mouse dx,dy]\n");
     return -1;
 }
@@ -109,6 +109,7 @@ int main(int argc, char **argv) {
         else if (ARG("--mode")) {
             const char *m = argv[++i];
             if (strcmp(m, "wave") == 0) mode = MORT_MODE_WAVE;
+            else if (strcmp(m, "throughput") == 0) mode = MORT_MODE_THROUGHPUT; /* non-parity: own streams per (pixel, stratum row) */
             else if (strcmp(m, "host") == 0) host_mode = 1;
             else if (strcmp(m, "mega") != 0) { fprintf(stderr, "unknown mode %s\n", m); return -1; }
         }
@@ -256,7 +257,7 @@ int main(int argc, char **argv) {
     printf("{\"scene\": %d, \"width\": %d, \"height\": %d, \"spp_nominal\": %d, \"spp_effective\": %d, \"depth\": %d, \"mode\": \"%s\", \"gpus\": %d, "
            "\"seconds\": %.6f, \"msamples_per_s\": %.3f, \"kernel_seconds\": %.6f, \"gather_seconds\": %.6f, \"segments\": %llu, "
            "\"algorithmic_hbm_bytes\": %llu, \"hbm_GBps\": %.4g, \"hbm_frac_of_8TBps\": %.3g, \"reference_walks\": %llu, \"kernel\": \"%s\"}\n",
-           scene, W, H, cam.samples_per_pixel, eff, cam.bounce_limit, host_mode ? "host" : mode == MORT_MODE_WAVE ? "wave" : "mega", gpus, sec,
+           scene, W, H, cam.samples_per_pixel, eff, cam.bounce_limit, host_mode ? "host" : mode == MORT_MODE_WAVE ? "wave" : mode == MORT_MODE_THROUGHPUT ? "throughput (non-parity)" : "mega", gpus, sec,
            (double)npx * eff / sec / 1e6, stats.seconds, stats.gather_seconds, (unsigned long long)stats.segments,
            (unsigned long long)stats.algorithmic_hbm_bytes, stats.algorithmic_hbm_bytes / stats.seconds / 1e9,
            stats.algorithmic_hbm_bytes / stats.seconds / 8e12, (unsigned long long)stats.reference_walks, stats.kernel_name);
