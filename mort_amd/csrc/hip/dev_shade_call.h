@@ -7,10 +7,13 @@
 
 #include "dev_shade.h"
 
-/* Shading is out of line: one call per segment with everything passed in registers.  (Inlined into the state loop, hipcc 7.2
- * -O3 produced a kernel whose scattered-ray origin was wrong for a few rays per thousand -- correct at -O1, correct with
- * a printf next to it, correct out of line; the parity tests against the oracle are what guards this.)  It also keeps the
- * shade step's registers out of the traversal steps.  wave_gen.hip's shade kernel showed the same symptom inlined. */
+/* Shading is out of line: one call per segment with everything passed in registers.  Inlined into the state loop, hipcc 7.2 -O3
+ * produced a kernel whose scattered-ray origin was wrong for a few rays per thousand.  Pass bisection (-mllvm -opt-bisect-limit,
+ * scripts/bisect_build.sh + bisect_check.py, on wf_shade_gen) puts the first bad pass at SLPVectorizerPass on the kernel; it is not the
+ * packed-fp32 lowering (still wrong with -packed-fp32-ops off) and not type-based aliasing (still wrong with -fno-strict-aliasing).
+ * The build now carries -fno-slp-vectorize, with which the inlined form (-DMORT_SHADE_INLINE) is bit-exact on every GPU test -- and
+ * no faster (final scene 800x800x100: 439 vs 442 ms), so the call stays: it keeps the shade step's registers out of the traversal
+ * steps (186 vs 193 VGPRs).  The parity tests against the oracle are what guards this. */
 struct ShadeRet { float ox, oy, oz, dx, dy, dz, tm, kx, ky, kz, rp, fx, fy, fz; int flags; uint32_t d, v0, v1, v2, v3, v4, draws; };
 static __device__ __attribute__((noinline)) ShadeRet shade_call(const DScene *scp, int light_type, int light_idx, float ox, float oy, float oz, float dx, float dy, float dz, float tm,
                                                          float time0, float t, int kind, int prim, int cf, int cc, uint32_t d, uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4, uint32_t draws) {

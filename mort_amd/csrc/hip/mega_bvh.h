@@ -300,12 +300,15 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
 }
 
 /* PROBE = true is the 1-sample cost probe (its own symbol, so profiles keep the frame kernel's durations apart) */
-/* DRAIN = true adds the drain mode below (chain-bound partitions; it costs the throughput-bound frame 5 % in registers) */
+/* DRAIN = true adds the drain mode below (chain-bound partitions; it costs the throughput-bound frame 5 % in registers).  A chain-bound
+ * launch is latency-bound -- the frame ends when its longest pixel chain does, at the pace of one wave -- so its smaller workgroups are
+ * compiled for the waves per SIMD they bring themselves (256 threads: 1, 384 / 512: 2) and keep the whole state in registers: no spills,
+ * whose scratch latency a lone wave cannot hide */
 /* SUB = true: MORT_MODE_THROUGHPUT's launch over (pixel, stratum row) work items with their own streams (FastArgs.sub) -- labelled, never parity.
  * (A thin wrapper kernel around a shared body would keep the three-parameter symbol names, but it perturbs the frame kernel's register
  * allocation: 136 instead of 122 scratch instructions) */
 template <int BLOCK, bool PROBE, bool DRAIN = false, bool SUB = false>
-__global__ void __launch_bounds__(BLOCK, MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
+__global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) / 256 : MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const RenderArgs &a = fa.r;
     {

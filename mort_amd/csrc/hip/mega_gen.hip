@@ -239,7 +239,11 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         /* out of line (dev_shade_call.h): inlined here, hipcc 7.2 -O3 gives wrong scattered-ray origins for a few rays per
                          * thousand (identical wrong bits with asm barriers around it, with guarded chain loops, with the scene read from
                          * HBM or LDS; correct at -O1 and with a printf next to it) -- kept out of line, guarded by the parity tests */
+#ifdef MORT_SHADE_INLINE
+                        const ShadeOut so = shade_hit(s_lsc, a.light_type, a.light_idx, ray, ray_time0, b, rng);
+#else
                         const ShadeOut so = shade_hit_outlined(&s_lsc, a.light_type, a.light_idx, ray, ray_time0, b, rng);
+#endif
 #ifdef MORT_DEBUG_PRINT
                         if (lofs == a.debug_lofs) printf("   shaded: done %d ident %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", (int)so.done, (int)so.ident, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
 #endif

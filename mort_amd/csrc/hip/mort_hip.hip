@@ -696,7 +696,9 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         else {
             const int cand[4] = {768, 512, 384, 256};
             FB = 256;
-            for (int k = 0; k < 4; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; }
+            /* about one pixel per lane or fewer: the frame is as long as its longest pixel chain, so take the drain kernels that are
+             * compiled without spills (<= 512 threads; one rank of 4 at 1200x675: 81 ms vs 90 ms with 768) */
+            for (int k = (px_per_lane < 1.5 && !substream) ? 1 : 0; k < 4; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; }
         }
         void (*kern)(const FastArgs) = nullptr, (*kern_probe)(const FastArgs) = nullptr;
         /* chain-bound partition (about one pixel per lane or fewer): drain mode + spread fetches (mega_bvh.h) */
@@ -732,6 +734,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, FB, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 1;
+        { const char *pc = std::getenv("MORT_FAST_BLOCKS_PER_CU"); if (pc && std::atoi(pc) >= 1 && std::atoi(pc) < per_cu) per_cu = std::atoi(pc); }
         int grid = c->num_cus * per_cu;
         const int want_blocks = (int)((lanes_wanted + FB - 1) / FB);
         if (grid > want_blocks) grid = want_blocks;

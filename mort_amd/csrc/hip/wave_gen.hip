@@ -303,7 +303,11 @@ __global__ void __launch_bounds__(256) wf_shade_gen(const WfGenArgs w) {
         bool terminated = (best == GBEST_NONE);
         if (!terminated) {
             const Best bb = gen_decode_best(sc, chains, best, closest);
+#ifdef MORT_SHADE_INLINE /* diagnostic builds only: reproduces the wrong scattered-ray origins (dev_shade_call.h) */
+            const ShadeOut so = shade_hit(a.sc, a.light_type, a.light_idx, ray, time0, bb, rng);
+#else
             const ShadeOut so = shade_hit_outlined(&a.sc, a.light_type, a.light_idx, ray, time0, bb, rng);
+#endif
             if (so.done) { final_value = so.final_value; terminated = true; }
             else {
                 float4 e; e.x = so.e.kx; e.y = so.e.ky; e.z = so.e.kz; e.w = so.e.rp; /* dielectric: (1, 1, 1, 1) */
