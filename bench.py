@@ -149,13 +149,21 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback for the render path)")
+    # MORT_BENCH_REHEARSAL=1: every rank on GPU 0 and the gather through gloo (host staging) -- a rehearsal of the N-rank control flow
+    # on a one-GPU box, where RCCL refuses ranks that share a device; its timings mean nothing and the line says so
+    rehearsal = os.environ.get("MORT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
 
     # ---- scene, upload, seed (outside the timed region) ----
     world, cam = host.build_scene(args.scene, width=args.width, spp=args.spp, depth=args.depth, aspect=args.aspect)
@@ -168,6 +176,7 @@ def main():
     lr = ctx.local_rows(H)
     fg = partition.FrameGather(H, W, 4, torch.uint8, rank, world_size, args.rows_per_block, dev)
     tile = fg.tile  # packed owned rows (padded so every rank's tile has the same shape)
+    fg_host = partition.FrameGather(H, W, 4, torch.uint8, rank, world_size, args.rows_per_block, torch.device("cpu")) if rehearsal else None
 
     # a non-default torch stream: its handle is what the C ABI launches on, and torch.cuda.Event /
     # torch.distributed both follow torch's *current* stream, so everything below runs under it
@@ -188,7 +197,10 @@ def main():
         if record:
             e1.record(stream)
             ev_pairs.append((e0, e1))
-        if world_size > 1:
+        if world_size > 1 and rehearsal:
+            fg_host.tile.copy_(tile)  # blocking D2H on the current stream, then gloo
+            fg_host.gather(dist)
+        elif world_size > 1:
             fg.gather(dist)  # RCCL gather of the packed uchar4 rows + de-interleave on rank 0
         # N == 1: `tile` already is the full framebuffer (rank 0 owns every row)
 
@@ -219,7 +231,7 @@ def main():
             step(False, hip.MODE_THROUGHPUT)
         sync_all()
         elapsed_tp = time.perf_counter() - t1
-    t = torch.tensor([elapsed, elapsed_tp or 0.0], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, elapsed_tp or 0.0], dtype=torch.float64, device=torch.device("cpu") if rehearsal else dev)
     if world_size > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t[0].item())
@@ -227,6 +239,19 @@ def main():
 
     # one more frame through the blocking entry to read the library's own counters/HIP-event time
     st = ctx.render_device(cam, tile.data_ptr(), 0, stream.cuda_stream, mode=mode, sync=True)
+
+    rehearsal_ok = None
+    if rehearsal and world_size > 1:  # the composed frame must be the single-rank frame
+        step(False, mode)
+        sync_all()
+        if rank == 0:
+            composed = fg_host.frame.clone()
+            with hip.Context(0) as solo:
+                solo.upload_world(world)
+                solo.rng_seed(69420, W, H)
+                for _ in range(args.warmup + args.steps + 2 + (0 if elapsed_tp is None else 0)):
+                    ref = solo.render(cam, mode=mode, want_accum=False)["rgba"]
+            rehearsal_ok = bool((composed.numpy() == ref).all())
 
     if rank == 0:
         samples_per_step = W * H * eff
@@ -274,6 +299,9 @@ def main():
             "kernel": {"segments_per_frame": st["segments"], "segments_per_s": st["segments"] / st["seconds"],
                        "hip_event_seconds": st["seconds"], "vgprs": st["kernel_vgprs"], "lds_bytes": st["kernel_lds_bytes"]},
         }
+        if rehearsal:
+            out["rehearsal"] = {"note": "MORT_BENCH_REHEARSAL=1: all ranks on GPU 0, gather through gloo -- control-flow rehearsal, timings meaningless",
+                                "composed_frame_equals_single_rank": rehearsal_ok}
         if elapsed_tp:
             out["nonparity_throughput_mode"] = {
                 "value": samples_per_step * args.steps / elapsed_tp / 1e6, "unit": "Msamples/s", "ms_per_step": elapsed_tp / args.steps * 1e3,
