@@ -19,8 +19,12 @@
 
 struct PixelTotals { uint32_t segments, draws; };
 
+/* lds_stack (device only): the first lds_levels bounce-stack levels of this lane live at lds_stack[level * lds_stride], the rest in the
+ * private array (mega_kernel: 12 levels x 256 lanes x 16 B; the unwind reads them back one dependent level at a time, which from
+ * private memory costs an L2 round trip per level).  The host loop passes none. */
 template <bool TREE>
-DEV PixelTotals render_pixel(const RenderArgs &a, const GenWalk *gw, int x, int ly, unsigned long long *scans) {
+DEV PixelTotals render_pixel(const RenderArgs &a, const GenWalk *gw, int x, int ly, unsigned long long *scans, float4 *lds_stack = nullptr, int lds_levels = 0,
+                             int lds_stride = 0) {
     const DScene &sc = a.sc;
     const int y = global_row(ly, a.rank, a.nranks, a.rows_per_block);
     const int lofs = x + ly * a.width;
@@ -73,6 +77,7 @@ DEV PixelTotals render_pixel(const RenderArgs &a, const GenWalk *gw, int x, int 
                 if (so.done) { final_value = so.final_value; done = true; }
                 else {
                     if (so.ident) ident_mask |= (1ull << iter);
+                    else if (iter < lds_levels) { float4 e4; e4.x = so.e.kx; e4.y = so.e.ky; e4.z = so.e.kz; e4.w = so.e.rp; lds_stack[iter * lds_stride] = e4; }
                     else stack[iter] = so.e;
                     iter++;
                 }
@@ -82,7 +87,9 @@ DEV PixelTotals render_pixel(const RenderArgs &a, const GenWalk *gw, int x, int 
             while (iter > 0) {
                 iter--;
                 if ((ident_mask >> iter) & 1ull) { final_value = vadd(mk(0, 0, 0), final_value); continue; }
-                const StackEntry e = stack[iter];
+                StackEntry e;
+                if (iter < lds_levels) { const float4 e4 = lds_stack[iter * lds_stride]; e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w; }
+                else e = stack[iter];
                 const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
                 final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
             }

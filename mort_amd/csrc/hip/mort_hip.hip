@@ -41,6 +41,9 @@
 #ifndef MORT_GENERIC_WAVES
 #define MORT_GENERIC_WAVES 3
 #endif
+#ifndef MORT_MEGA_LDS_LEVELS
+#define MORT_MEGA_LDS_LEVELS 12
+#endif
 extern "C" __global__ void __launch_bounds__(256, MORT_GENERIC_WAVES)
 mega_kernel(const RenderArgs a) {
     const int lane = threadIdx.x & 63;
@@ -52,7 +55,8 @@ mega_kernel(const RenderArgs a) {
     const bool active = (x < a.width) && (ly < a.local_rows);
     if (!active) return;
 
-    const PixelTotals t = render_pixel<false>(a, nullptr, x, ly, nullptr); /* dev_pixel.h: the body the host loop runs too */
+    __shared__ float4 s_stack[MORT_MEGA_LDS_LEVELS * 256]; /* bounce-stack levels 0..11 of the block's 256 lanes: 48 KB, three blocks per CU */
+    const PixelTotals t = render_pixel<false>(a, nullptr, x, ly, nullptr, s_stack + threadIdx.x, MORT_MEGA_LDS_LEVELS, 256); /* dev_pixel.h: the body the host loop runs too */
     atomicAdd(&a.counters[0], (unsigned long long)t.segments);
     atomicAdd(&a.counters[1], (unsigned long long)t.draws);
 }
