@@ -178,16 +178,16 @@ DEV bool slab_check(const DBvhNode &nd, const Ray &ray, const OwnRay &r, float c
 enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 
 #ifndef MORT_TH_S
-#define MORT_TH_S 40
+#define MORT_TH_S 48
 #endif
 #ifndef MORT_TH_L
-#define MORT_TH_L 24
+#define MORT_TH_L 16
 #endif
 #ifndef MORT_T_UNROLL
 #define MORT_T_UNROLL 2 /* box steps per check of the lane count */
 #endif
 #ifndef MORT_T_KEEP
-#define MORT_T_KEEP 12
+#define MORT_T_KEEP 16
 #endif
 
 #ifndef MORT_MIN_WAVES

@@ -782,7 +782,8 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
                   * registers and the final scene is 9 % slower); fewer pixels than lanes: 256-thread groups so every CU has work */
                  FB = (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
         if (FB != 768 && FB != 512 && FB != 256) FB = 256;
-        fa.th_s = MORT_TH_S; fa.th_l = MORT_TH_L; fa.t_keep = MORT_T_KEEP; ga.th_m = 24;
+        /* swept on the final scene, 800x800x100 (scripts/th_sweep.py, 180 settings): 373 ms here vs 449 ms with the BVH kernel's (40,24,12) and m = 24 */
+        fa.th_s = 28; fa.th_l = 20; fa.t_keep = 4; ga.th_m = 56;
         { const char *lw = std::getenv("MORT_GEN_LANE_WALK"); ga.lane_walk = lw ? std::atoi(lw) : 0; }
         { const char *th = std::getenv("MORT_GEN_THRESHOLDS"); /* "s,l,k,m" */
           if (th) { int s_ = 0, l_ = 0, k_ = 0, m_ = 0; if (std::sscanf(th, "%d,%d,%d,%d", &s_, &l_, &k_, &m_) == 4) { fa.th_s = s_; fa.th_l = l_; fa.t_keep = k_; ga.th_m = m_; } } }
