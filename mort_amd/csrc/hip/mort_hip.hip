@@ -663,6 +663,9 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         GenArgs ga = c->gen;
         ga.f.r = a;
         ga.f.hot_src = (const unsigned char *)c->d_gen; ga.f.hot_bytes = c->gen_bytes;
+        ga.f.th_s = 32; ga.f.th_l = 24; ga.f.t_keep = 16; /* wf_trav_gen's retire+refill / leaf / box-run thresholds */
+        { const char *th = std::getenv("MORT_WAVE_THRESHOLDS"); /* "f,l,k" */
+          if (th) { int f_ = 0, l_ = 0, k_ = 0; if (std::sscanf(th, "%d,%d,%d", &f_, &l_, &k_) == 3) { ga.f.th_s = f_; ga.f.th_l = l_; ga.f.t_keep = k_; } } }
         if (!c->h_live) HIPCHK(c, hipHostMalloc((void **)&c->h_live, 64));
         WfGenHost hb;
         hb.d_wf = &c->d_wf; hb.wf_bytes = &c->wf_bytes; hb.h_live = &c->h_live; hb.fronts = &c->wf_fronts; hb.num_cus = c->num_cus;

@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
     unsigned next_batch = wave_id, b_base = 0;
     int b_cnt = 0, b_off = 0;
 
+    const int th_f = fa.th_s, th_l = fa.th_l, t_keep = fa.t_keep; /* scheduling thresholds (lanes), as in mega_gen.hip; F plays S's part */
     int state = W_F;
     bool have = false;
     unsigned pos = 0;
@@ -142,8 +143,8 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
         const int nF = __popcll(__ballot(state == W_F));
         if (nT + nL + nF == 0) break;
         int pick;
-        if (nF >= 32) pick = W_F;
-        else if (nL >= 24) pick = W_L;
+        if (nF >= th_f) pick = W_F;
+        else if (nL >= th_l) pick = W_L;
         else if (nT > 0) pick = W_T;
         else pick = (nL >= nF) ? W_L : W_F;
 
@@ -168,7 +169,7 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
                     else { node = next & 0x7fffu; if (next & 0x8000u) state = W_L; }
                 }
                 keep = __popcll(__ballot(state == W_T));
-            } while (keep >= 16);
+            } while (keep >= t_keep);
         } else if (pick == W_L) {
             uint32_t lpos = 0;
             int cnt = 0;
