@@ -109,6 +109,31 @@ DEV void gen_leaf_test(const DScene &sc, const int *chains, const uint32_t *rank
     }
 }
 
+/* the same test with the primitive's record already in registers (the leaf loops load the next record while they test this one) */
+DEV void gen_leaf_test_rec(const DScene &sc, const int *chains, const uint32_t *ranks, int n_spheres, const DSphere &sp, const DQuad &qd, uint32_t e,
+                           const Ray &ray, float ray_a, float &closest, uint32_t &best, int &flags) {
+    const uint32_t cid = GENT_CHAIN(e);
+    Ray r = ray;
+    float ra = ray_a;
+    if (cid != 0) {
+        r = apply_chain(sc, ray, chains[2 * cid], chains[2 * cid + 1]);
+        ra = vlen2(r.d);
+    }
+    float t;
+    if (GENT_QUAD(e)) {
+        float al, be;
+        if (!quad_hit_t(qd, r, 0.001f, closest, t, al, be)) t = -1.0f;
+    } else {
+        t = gen_sphere_root(sp, r, ra, 0.001f, closest);
+    }
+    if (t != -1.0f) {
+        if (!(t == t)) flags |= GFL_REF;
+        const bool tie = (t == closest) && (best != GBEST_NONE);
+        if (!tie || gen_rank(ranks, n_spheres, e) > gen_rank(ranks, n_spheres, best)) best = e;
+        closest = t;
+    }
+}
+
 /* world::hit's scan over the solids as the reference runs it (world.cuh:122-168 through the flattened items): the exact
  * answer for the rays the tree walk does not decide */
 DEV void gen_scan_solids(const DScene &sc, int first_medium, const int *chains, int n_chains, const Ray &r, float &closest, uint32_t &best) {

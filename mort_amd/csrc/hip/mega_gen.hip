@@ -120,12 +120,17 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
 
 #ifdef MORT_PROFILE_STATES
     unsigned long long gp_steps[4] = {0, 0, 0, 0}, gp_lanes[4] = {0, 0, 0, 0}, gp_cyc[5] = {0, 0, 0, 0, 0}, gp_lprims = 0, gp_liters = 0;
+    unsigned long long gp_sp[4] = {0, 0, 0, 0}, gps0 = 0, gps1; /* S parts: shade, finish, new pixel, new ray */
     unsigned long long gpt0 = __builtin_readcyclecounter(), gpt1;
+#define GPROFS0() do { gps0 = __builtin_readcyclecounter(); } while (0)
+#define GPROFS(i) do { gps1 = __builtin_readcyclecounter(); gp_sp[i] += gps1 - gps0; gps0 = gps1; } while (0)
 #define GPROF(i, lanes) do { gp_steps[i] += 1; gp_lanes[i] += (unsigned long long)(lanes); } while (0)
 #define GPROFC(i) do { gpt1 = __builtin_readcyclecounter(); gp_cyc[i] += gpt1 - gpt0; gpt0 = gpt1; } while (0)
 #else
 #define GPROF(i, lanes) do { } while (0)
 #define GPROFC(i) do { } while (0)
+#define GPROFS0() do { } while (0)
+#define GPROFS(i) do { } while (0)
 #endif
     for (;;) {
         const unsigned long long mT = __ballot(state == G_T);
@@ -177,12 +182,28 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
             uint32_t pos = 0;
             int cnt = 0;
             if (state == G_L) { const uint32_t rec = leaves[node]; pos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
+#ifndef MORT_GEN_NO_PREFETCH
+            /* the record of the NEXT primitive is requested before this one is tested: with the primitives in HBM / L2 (the final scene's
+             * 2 401 quads do not fit in LDS) a leaf is otherwise a chain of dependent load -> test -> load */
+            uint32_t e_next = 0;
+            DSphere sp_next; DQuad qd_next;
+            sp_next.cx = sp_next.cy = sp_next.cz = sp_next.radius = sp_next.vx = sp_next.vy = sp_next.vz = 0; sp_next.mat = 0;
+            qd_next = quads[0];
+            if (cnt > 0) { e_next = entries[pos]; if (GENT_QUAD(e_next)) qd_next = quads[GENT_IDX(e_next)]; else sp_next = spheres[GENT_IDX(e_next)]; }
+#endif
             while (__ballot(cnt > 0) != 0ull) {
 #ifdef MORT_PROFILE_STATES
                 gp_liters++; gp_lprims += (unsigned long long)__popcll(__ballot(cnt > 0));
 #endif
                 if (cnt > 0) {
+#ifndef MORT_GEN_NO_PREFETCH
+                    const uint32_t e = e_next;
+                    const DSphere sp_cur = sp_next; const DQuad qd_cur = qd_next;
+                    if (cnt > 1) { e_next = entries[pos + 1]; if (GENT_QUAD(e_next)) qd_next = quads[GENT_IDX(e_next)]; else sp_next = spheres[GENT_IDX(e_next)]; }
+                    gen_leaf_test_rec(lsc, chains, ga.ranks, ga.n_spheres, sp_cur, qd_cur, e, ray, ray_a, closest, best, flags);
+#else
                     gen_leaf_test(lsc, chains, ga.ranks, ga.n_spheres, spheres, quads, entries[pos], ray, ray_a, closest, best, flags);
+#endif
                     pos++; cnt--;
                 }
             }
@@ -214,6 +235,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
         } else {
             GPROF(3, nS);
             /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
+            GPROFS0();
             if (state == G_S) {
                 if (kind == K_SHADE) {
                     if (flags) { /* worlds without media come here directly */
@@ -257,18 +279,33 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         }
                     }
                 }
+                GPROFS(0);
                 if (kind == K_FINISH) { /* unwind + accumulate (camera.cuh:165-173,190); see mega_bvh.h for the identity levels */
                     if (iter > 0) {
                         unsigned long long todo = ~ident_mask & (iter >= 64 ? ~0ull : ((1ull << iter) - 1ull));
                         if ((ident_mask >> (iter - 1)) & 1ull) final_value = vadd(mk(0, 0, 0), final_value);
+                        /* four levels are fetched before they are applied (deepest first, as the reference unwinds): the deep levels live in
+                         * private memory, and one dependent load per level made a long path's unwind a chain of L2 round trips */
                         while (todo != 0ull) {
-                            const int lvl = 63 - __builtin_clzll(todo);
-                            todo &= ~(1ull << lvl);
-                            StackEntry e;
-                            if (lvl < DL) { const float4 e4 = stack_lds[lvl * BLOCK + threadIdx.x]; e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w; }
-                            else e = stack_deep[lvl];
-                            const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
-                            final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
+                            StackEntry e[4];
+                            int n = 0;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (todo != 0ull) {
+                                    const int lvl = 63 - __builtin_clzll(todo);
+                                    todo &= ~(1ull << lvl);
+                                    if (lvl < DL) { const float4 e4 = stack_lds[lvl * BLOCK + threadIdx.x]; e[k].kx = e4.x; e[k].ky = e4.y; e[k].kz = e4.z; e[k].rp = e4.w; }
+                                    else e[k] = stack_deep[lvl];
+                                    n = k + 1;
+                                }
+                            }
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (k < n) {
+                                    const V3 t = vmul(mk(e[k].kx, e[k].ky, e[k].kz), final_value);
+                                    final_value = vadd(mk(0, 0, 0), vscale(e[k].rp, t));
+                                }
+                            }
                         }
                         iter = 0;
                     }
@@ -284,6 +321,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         kind = K_NEWPIX;
                     }
                 }
+                GPROFS(1);
                 if (kind == K_NEWPIX) {
                     const PixelFetch pf = pixel_fetch(&fa, total_q);
                     if (!pf.got) state = G_DONE;
@@ -297,6 +335,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         if (spp <= 0) final_value = mk(0, 0, 0);
                     }
                 }
+                GPROFS(2);
                 if (state != G_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
                         ray = get_ray(a, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
@@ -340,6 +379,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                     }
                 }
             }
+            GPROFS(3);
             GPROFC(3);
         }
     }
@@ -348,6 +388,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
         for (int k = 0; k < 4; k++) { atomicAdd(&a.counters[4 + 2 * k], gp_steps[k]); atomicAdd(&a.counters[5 + 2 * k], gp_lanes[k]); }
         for (int k = 0; k < 5; k++) atomicAdd(&a.counters[12 + k], gp_cyc[k]);
         atomicAdd(&a.counters[17], gp_liters); atomicAdd(&a.counters[18], gp_lprims);
+        for (int k = 0; k < 4; k++) atomicAdd(&a.counters[20 + k], gp_sp[k]);
     }
 #endif
 }
