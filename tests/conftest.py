@@ -11,6 +11,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch bundles its own HIP runtime: if libmort_hip.so (linked to /opt/rocm's) initialises HIP first, torch.cuda later reports
+    # "No HIP GPUs are available".  The tests that hand torch tensors to the C ABI need torch's runtime up first, whatever subset runs.
+    try:
+        import torch  # noqa: F401
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     # build the CPU pieces once (host scene layer + oracle); the HIP library is built by
     # __graft_entry__.build() / `make hip` and must already exist for the gpu tests
     need = [os.path.join(ROOT, "mort_amd", "lib", "libmort_host.so"), os.path.join(ROOT, "oracle", "libmort_oracle.so")]
