@@ -304,10 +304,14 @@ __global__ void __launch_bounds__(256) wf_shade_gen(const WfGenArgs w) {
         bool terminated = (best == GBEST_NONE);
         if (!terminated) {
             const Best bb = gen_decode_best(sc, chains, best, closest);
-#ifdef MORT_SHADE_INLINE /* diagnostic builds only: reproduces the wrong scattered-ray origins (dev_shade_call.h) */
-            const ShadeOut so = shade_hit(a.sc, a.light_type, a.light_idx, ray, time0, bb, rng);
-#else
+            /* inlined: this kernel waits on memory (71 % of its wave cycles), and the out-of-line call's frame -- callee-saved registers and
+             * the 22-dword result through scratch -- was half of its memory instructions: 2048x2048x4 spp 223 -> 112 ms.  (The call was a
+             * workaround for the SLP vectorizer's miscompile, dev_shade_call.h; the library is built without that pass now.  -DMORT_SHADE_CALL
+             * brings the call back; mega_gen.hip keeps it, where it costs nothing.) */
+#ifdef MORT_SHADE_CALL
             const ShadeOut so = shade_hit_outlined(&a.sc, a.light_type, a.light_idx, ray, time0, bb, rng);
+#else
+            const ShadeOut so = shade_hit(a.sc, a.light_type, a.light_idx, ray, time0, bb, rng);
 #endif
             if (so.done) { final_value = so.final_value; terminated = true; }
             else {

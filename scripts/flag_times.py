@@ -13,7 +13,7 @@ if os.environ.get("FLAG_TIMES_CHILD"):
         ctx.set_partition(0, n, 8); ctx.upload_world(world); ctx.rng_seed(S.DEFAULT_SEED, cam.image_width, cam.image_height)
         ts = []
         for f in range(4):
-            out = ctx.render(cam, want_accum=False); ts.append(out["stats"]["seconds"] * 1e3)
+            out = ctx.render(cam, mode=(hip.MODE_WAVE if os.environ.get("FLAG_MODE") == "wave" else hip.MODE_MEGA), want_accum=False); ts.append(out["stats"]["seconds"] * 1e3)
     print(json.dumps({"ms": round(min(ts[1:]), 2), "kernel": out["stats"]["kernel_name"], "vgprs": out["stats"]["kernel_vgprs"], "segments": out["stats"]["segments"],
                       "sha": hashlib.sha1(out["rgba"].tobytes()).hexdigest()[:12]}))
     sys.exit(0)
