@@ -471,8 +471,8 @@ hipError_t mort_wave_gen_render(const GenArgs &ga, const WfGenHost &hb, int boun
     long long front = 0;
     const int chunk = 32; /* fronts per host round trip (the live count is read back in between) */
     while (live > 0 && front < max_fronts) {
-        /* a wave's share should hold at least two 64-record batches: fewer, fuller workgroups on small fronts */
-        int tg = (int)((live + (size_t)(TB / 64) * 128 - 1) / ((size_t)(TB / 64) * 128));
+        /* a wave's share of a front: one 64-record batch at least (two were 4 % slower on small fronts: the front's time is its slowest wave's) */
+        int tg = (int)((live + (size_t)(TB / 64) * 64 - 1) / ((size_t)(TB / 64) * 64));
         if (tg > max_trav_grid) tg = max_trav_grid;
         if (tg < 1) tg = 1;
         const int sg = (int)((live + 255) / 256) + 3;
