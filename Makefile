@@ -49,7 +49,7 @@ $(LIBDIR)/libmort_hip.so: $(HIP_OBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-rdc -shared -o $@ $(HIP_OBJ) -lpthread -ldl
 
 oracle:
-	$(MAKE) -C oracle
+	$(MAKE) -C oracle all ref
 
 cli: $(BINDIR)/mort
 $(BINDIR)/mort: mort_amd/csrc/cli/mort.c $(LIBDIR)/libmort_host.so $(LIBDIR)/libmort_hip.so

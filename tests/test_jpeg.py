@@ -41,3 +41,29 @@ def test_rejects_what_it_does_not_decode(tmp_path):
     trunc.write_bytes(data[:200])
     assert _decode(str(trunc)) is None
     assert _decode(str(tmp_path / "missing.jpg")) is None
+
+
+def test_live_reference_decoder_agrees_when_built(tmp_path):
+    """oracle/_ref/stb_decode is the reference's own vendored stb_image compiled from where it lies (oracle/Makefile `ref`; only where
+    /root/reference exists).  When it is there, its output must be the committed fixture and the product decoder's output."""
+    import subprocess
+    import pytest
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "stb_decode")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref not built here (no /root/reference)")
+    ppm = tmp_path / "ref.ppm"
+    subprocess.check_call([exe, os.path.join(HERE, "golden", "earthmap.jpg"), str(ppm)])
+    raw = ppm.read_bytes()
+    assert raw.startswith(b"P6")
+    header, n = [], 0
+    pos = 0
+    while len(header) < 4:  # magic, width, height, maxval
+        end = pos
+        while raw[end:end + 1] not in (b" ", b"\n", b"\t", b"\r"):
+            end += 1
+        header.append(raw[pos:end]); pos = end + 1
+    w, h = int(header[1]), int(header[2])
+    ref = np.frombuffer(raw[pos:pos + w * h * 3], dtype=np.uint8).reshape(h, w, 3)
+    want = np.load(os.path.join(HERE, "golden", "earthmap_rgb.npz"))["rgb"]
+    assert (ref == want).all()
+    assert (_decode(os.path.join(HERE, "golden", "earthmap.jpg")) == ref).all()
