@@ -53,8 +53,8 @@ typedef enum mort_status {
                                  * makes a pixel's samples one serial chain; this mode keys one stream per (pixel, stratum row) -- subsequence x + (y*sqrt_spp + s_j)*W of
                                  * the same seed -- so a pixel's sqrt_spp rows run as independent work items, and a resolve kernel sums them in order.  Same estimator,
                                  * same per-sample arithmetic, deterministic and partition-invariant, but different random numbers: images agree with MORT_MODE_MEGA only
-                                 * statistically.  Needs mort_hip_rng_seed (the seed is reused; rng_load'ed states are not); BVH-of-spheres worlds (scenes 1, 10),
-                                 * no light object, else MORT_ERR_UNSUPPORTED; the per-pixel states of the other modes are left untouched.  bench.py reports it only
+                                 * statistically.  Needs mort_hip_rng_seed (the seed is reused; rng_load'ed states are not); worlds the two LDS state-machine
+                                 * kernels take (scenes 1, 10; the final scenes 8, 9), else MORT_ERR_UNSUPPORTED; the per-pixel states of the other modes are left untouched.  bench.py reports it only
                                  * as a separately labelled line */
 #define MORT_MODE_WAVE 1 /* wavefront (queued) pipeline: every world the megakernels stage in LDS (all ten built-in scenes), else MORT_ERR_UNSUPPORTED; blocking */
 

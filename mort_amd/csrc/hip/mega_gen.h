@@ -27,8 +27,8 @@ struct GenArgs {
 };
 
 /* host side (mega_gen.hip) */
-int mort_gen_blocks_per_cu(int block, bool prims_in_lds, size_t lds_bytes);
+int mort_gen_blocks_per_cu(int block, bool prims_in_lds, size_t lds_bytes, bool sub = false);
 hipError_t mort_gen_launch(const GenArgs &ga, int block, int grid, size_t lds_bytes, hipStream_t s);
-hipError_t mort_gen_attributes(int block, bool prims_in_lds, hipFuncAttributes *out);
+hipError_t mort_gen_attributes(int block, bool prims_in_lds, hipFuncAttributes *out, bool sub = false);
 
 #endif

@@ -54,7 +54,8 @@ __device__ __attribute__((noinline)) ScanHit scan_solids(const DScene *scp, int 
     return h;
 }
 
-template <int BLOCK, bool PRIMS_LDS>
+/* SUB = true: MORT_MODE_THROUGHPUT's launch over (pixel, stratum row) work items with their own streams (mega_bvh.h FastArgs.sub) -- labelled, never parity */
+template <int BLOCK, bool PRIMS_LDS, bool SUB = false>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)) mega_gen_kernel(const GenArgs ga) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ DScene s_lsc; /* the scene view below, for the out-of-line shade call */
@@ -312,25 +313,32 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                     ident_mask = 0ull;
                     pixel_color = vadd(pixel_color, final_value);
                     s_ij++;
-                    if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
-                    if ((s_ij >> 16) < a.sqrt_spp) {
+                    bool more; /* samples left in this work item (SUB: one stratum row) */
+                    if constexpr (SUB) {
+                        more = (s_ij & 0xffff) != a.sqrt_spp;
+                    } else {
+                        if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
+                        more = (s_ij >> 16) < a.sqrt_spp;
+                    }
+                    if (more) {
                         kind = K_NEWSAMPLE;
                     } else {
-                        if (ga.probe) pixel_write<true>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        if constexpr (SUB) pixel_write<false, true>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        else if (ga.probe) pixel_write<true>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
                         else pixel_write<false>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
                         kind = K_NEWPIX;
                     }
                 }
                 GPROFS(1);
                 if (kind == K_NEWPIX) {
-                    const PixelFetch pf = pixel_fetch(&fa, total_q);
+                    const PixelFetch pf = pixel_fetch<SUB>(&fa, total_q);
                     if (!pf.got) state = G_DONE;
                     else {
                         xy = pf.xy; lofs = pf.lofs;
                         rng.d = pf.d; rng.v0 = pf.v0; rng.v1 = pf.v1; rng.v2 = pf.v2; rng.v3 = pf.v3; rng.v4 = pf.v4;
                         rng.draws = 0;
                         pixel_color = mk(0, 0, 0);
-                        s_ij = 0; segments = 0;
+                        s_ij = SUB ? ((pf.got - 1) << 16) : 0; segments = 0;
                         kind = (spp > 0) ? K_NEWSAMPLE : K_FINISH;
                         if (spp <= 0) final_value = mk(0, 0, 0);
                     }
@@ -395,7 +403,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
 
 /* ---- host side ---- */
 typedef void (*gen_kernel_t)(const GenArgs);
-static gen_kernel_t pick_kernel(int block, bool prims_in_lds) {
+static gen_kernel_t pick_kernel(int block, bool prims_in_lds, bool sub = false) {
+    if (sub) { /* the non-parity launch: 512- and 256-thread workgroups only */
+        if (block == 512) return prims_in_lds ? mega_gen_kernel<512, true, true> : mega_gen_kernel<512, false, true>;
+        if (block == 256) return prims_in_lds ? mega_gen_kernel<256, true, true> : mega_gen_kernel<256, false, true>;
+        return nullptr;
+    }
     switch (block) {
     case 768: return prims_in_lds ? mega_gen_kernel<768, true> : mega_gen_kernel<768, false>;
     case 512: return prims_in_lds ? mega_gen_kernel<512, true> : mega_gen_kernel<512, false>;
@@ -403,8 +416,8 @@ static gen_kernel_t pick_kernel(int block, bool prims_in_lds) {
     }
     return nullptr;
 }
-int mort_gen_blocks_per_cu(int block, bool prims_in_lds, size_t lds_bytes) {
-    gen_kernel_t k = pick_kernel(block, prims_in_lds);
+int mort_gen_blocks_per_cu(int block, bool prims_in_lds, size_t lds_bytes, bool sub) {
+    gen_kernel_t k = pick_kernel(block, prims_in_lds, sub);
     if (!k) return 0;
     if (hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return 0;
     int per_cu = 0;
@@ -412,15 +425,15 @@ int mort_gen_blocks_per_cu(int block, bool prims_in_lds, size_t lds_bytes) {
     return per_cu;
 }
 hipError_t mort_gen_launch(const GenArgs &ga, int block, int grid, size_t lds_bytes, hipStream_t s) {
-    gen_kernel_t k = pick_kernel(block, ga.prims_in_lds != 0);
+    gen_kernel_t k = pick_kernel(block, ga.prims_in_lds != 0, ga.f.sub > 0);
     if (!k) return hipErrorInvalidValue;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3(grid), dim3(block), lds_bytes, s, ga);
     return hipGetLastError();
 }
-hipError_t mort_gen_attributes(int block, bool prims_in_lds, hipFuncAttributes *out) {
-    gen_kernel_t k = pick_kernel(block, prims_in_lds);
+hipError_t mort_gen_attributes(int block, bool prims_in_lds, hipFuncAttributes *out, bool sub) {
+    gen_kernel_t k = pick_kernel(block, prims_in_lds, sub);
     if (!k) return hipErrorInvalidValue;
     return hipFuncGetAttributes(out, (const void *)k);
 }

@@ -652,7 +652,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         }
     }
     if (substream) {
-        if (!use_fast || d_segpx) return MORT_ERR_UNSUPPORTED;
+        if (!(use_fast || use_gen) || d_segpx) return MORT_ERR_UNSUPPORTED; /* the two LDS state-machine kernels only */
         if (!c->seed_known) return MORT_ERR_NO_RNG;
         if ((long long)a.local_rows * cam->sqrt_spp >= 32768ll * 64) return MORT_ERR_CAPACITY;
         int st_s = ensure_substates(c, W, H, cam->sqrt_spp, s);
@@ -777,10 +777,11 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         fa.hot_src = (const unsigned char *)c->d_gen; fa.hot_bytes = c->gen_bytes;
         fa.next_q = (unsigned int *)(c->d_counters + 2);
         fa.tiles_x = (W + 7) / 8; fa.tiles_total = tiles;
+        if (substream) { fa.sub = cam->sqrt_spp; fa.vaccum = c->d_vaccum; fa.r.states = c->d_substates; }
         const long long lanes_wanted = (long long)tiles * 64;
         int FB = 768;
         { const char *fb_env = std::getenv("MORT_GEN_BLOCK_SIZE");
-          if (fb_env) FB = std::atoi(fb_env);
+          if (fb_env && !substream) FB = std::atoi(fb_env);
           else { /* 512 threads = 2 waves per SIMD: the state loop fits its 256-VGPR budget without spilling (at 3 waves it spills 44
                   * registers and the final scene is 9 % slower); fewer pixels than lanes: 256-thread groups so every CU has work */
                  FB = (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
@@ -800,7 +801,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         { const char *de = std::getenv("MORT_GEN_DL"); if (de && std::atoi(de) < dl) dl = std::atoi(de); }
         fa.off_stack = stack_off; fa.stack_lds_depth = dl;
         const size_t lds_bytes = (size_t)stack_off + (size_t)dl * FB * 16;
-        int per_cu = mort_gen_blocks_per_cu(FB, ga.prims_in_lds != 0, lds_bytes);
+        int per_cu = mort_gen_blocks_per_cu(FB, ga.prims_in_lds != 0, lds_bytes, substream);
         if (per_cu < 1) per_cu = 1;
         int grid = c->num_cus * per_cu;
         const int want_blocks = (int)((lanes_wanted + FB - 1) / FB);
@@ -808,8 +809,8 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         if (grid < 1) grid = 1;
         lds_bytes_used = (int)lds_bytes;
         gen_block_used = FB;
-        std::snprintf(kname, sizeof kname, "mega_gen_kernel<%d, %s>", FB, ga.prims_in_lds ? "true" : "false");
-        if (!std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
+        std::snprintf(kname, sizeof kname, substream ? "mega_gen_kernel<%d, %s, true>" : "mega_gen_kernel<%d, %s>", FB, ga.prims_in_lds ? "true" : "false");
+        if (!substream && !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
             int st_o = prepare_tile_order(c, cam, a, fa, tiles, grid, FB, false, s, [&](const FastArgs &pa) {
                 GenArgs pg = ga;
                 pg.f = pa;
@@ -820,6 +821,12 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
         }
         HIPCHK(c, mort_gen_launch(ga, FB, grid, lds_bytes, s));
+        if (substream) {
+            const int npx = W * a.local_rows;
+            hipLaunchKernelGGL(substream_resolve_kernel, dim3((npx + 255) / 256), dim3(256), 0, s, (const float *)c->d_vaccum, W, a.local_rows, cam->sqrt_spp,
+                               a.pixel_samples_scale, (uchar4 *)d_rgba, (float *)d_accum);
+            HIPCHK(c, hipGetLastError());
+        }
     } else if (blocks > 0) {
         hipLaunchKernelGGL(mega_kernel, dim3(blocks), dim3(64 * waves_per_block), 0, s, a);
         HIPCHK(c, hipGetLastError());
@@ -895,7 +902,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
                          : mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
                          : fast_kernel_used;
         const bool gen_ran = use_gen && mode != MORT_MODE_WAVE && gen_block_used > 0;
-        if ((gen_ran ? mort_gen_attributes(gen_block_used, c->gen.prims_in_lds != 0, &fattr) : hipFuncGetAttributes(&fattr, kf)) == hipSuccess) {
+        if ((gen_ran ? mort_gen_attributes(gen_block_used, c->gen.prims_in_lds != 0, &fattr, substream) : hipFuncGetAttributes(&fattr, kf)) == hipSuccess) {
             stats->kernel_vgprs = fattr.numRegs;
             stats->kernel_lds_bytes = (use_fast || gen_ran) ? lds_bytes_used : (int)fattr.sharedSizeBytes;
         }
