@@ -108,7 +108,8 @@ def test_gpu_cli_files_match_oracle(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scene,extra", [(1, []), (8, ["--depth", "6"]), (6, ["--mode", "wave"]), (1, ["--mode", "throughput"])])
+@pytest.mark.parametrize("scene,extra", [(1, []), (8, ["--depth", "6"]), (6, ["--mode", "wave"]), (1, ["--mode", "throughput"]),
+                                         (8, ["--depth", "6", "--mode", "throughput"])])
 def test_gpu_cli_two_ranks_compose_the_single_gpu_frame(tmp_path, scene, extra):
     """`--gpus 2`: two forked ranks (both on device 0 here, rows gathered through the shared mapping) = one rank."""
     one, two = tmp_path / "one.ppm", tmp_path / "two.ppm"
