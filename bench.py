@@ -220,9 +220,9 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = [a.elapsed_time(b) for a, b in ev_pairs]
-    # the labelled non-parity mode, timed the same way beside the headline (BVH-of-spheres worlds only); never `value`
+    # the labelled non-parity mode, timed the same way beside the headline (worlds of the two LDS state-machine kernels); never `value`
     elapsed_tp = None
-    if args.mode == "mega" and args.scene in (1, 10) and not args.no_throughput_line:
+    if args.mode == "mega" and args.scene in (1, 10, 8, 9) and not args.no_throughput_line:
         step(False, hip.MODE_THROUGHPUT)  # seeds the sub-streams
         step(False, hip.MODE_THROUGHPUT)
         sync_all()
