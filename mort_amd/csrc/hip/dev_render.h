@@ -37,7 +37,18 @@ DEV int global_row(int ly, int rank, int nranks, int rpb) {
 }
 
 /* ---- Camera::get_ray (camera.cuh:210-242) ---- */
-DEV Ray get_ray(const RenderArgs &a, int x, int y, Rng &rng, int s_i, int s_j) {
+/* the camera fields get_ray reads, for kernels that keep them in LDS: their argument struct has a private copy (out-of-line helpers take
+ * its address), and a new sample's ray otherwise starts with ten dependent loads from private memory */
+struct CamView {
+    float recip_sqrt_spp, defocus_angle;
+    V3 center, pixel00, du, dv, defocus_u, defocus_v;
+};
+DEV void cam_view_fill(CamView &c, const RenderArgs &a) {
+    c.recip_sqrt_spp = a.recip_sqrt_spp; c.defocus_angle = a.defocus_angle;
+    c.center = a.center; c.pixel00 = a.pixel00; c.du = a.du; c.dv = a.dv; c.defocus_u = a.defocus_u; c.defocus_v = a.defocus_v;
+}
+template <typename CAM>
+DEV Ray get_ray(const CAM &a, int x, int y, Rng &rng, int s_i, int s_j) {
     const double px = (double)(((float)s_i + random_float(rng)) * a.recip_sqrt_spp) - 0.5;
     const double py = (double)(((float)s_j + random_float(rng)) * a.recip_sqrt_spp) - 0.5;
     const float ox = (float)px, oy = (float)py;

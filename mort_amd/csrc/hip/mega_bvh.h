@@ -310,6 +310,7 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
 template <int BLOCK, bool PROBE, bool DRAIN = false, bool SUB = false>
 __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) / 256 : MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __shared__ CamView s_cam; /* dev_render.h: get_ray's camera fields, read from LDS */
     const RenderArgs &a = fa.r;
     {
         const uint4 *src = (const uint4 *)fa.hot_src;
@@ -317,6 +318,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
         const uint32_t n16 = fa.hot_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
     }
+    if (threadIdx.x == 0) cam_view_fill(s_cam, a);
     __syncthreads();
     const DNode2 *nodes2 = (const DNode2 *)(lds + fa.off_nodes2);
     const DBvhNode *leaves = (const DBvhNode *)(lds + fa.off_leaves);
@@ -639,7 +641,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                 if (state != ST_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
                         PROFB(4);
-                        ray = get_ray(a, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
+                        ray = get_ray(s_cam, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
                         ray_time0 = ray.tm;
                         iter = 0;
                         kind = K_SHADE;

@@ -59,6 +59,7 @@ template <int BLOCK, bool PRIMS_LDS, bool SUB = false>
 __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)) mega_gen_kernel(const GenArgs ga) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     __shared__ DScene s_lsc; /* the scene view below, for the out-of-line shade call */
+    __shared__ CamView s_cam;
     const FastArgs &fa = ga.f;
     const RenderArgs &a = fa.r;
     {
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
         lsc.list_types = (const int *)(lds + ga.o_ltypes); lsc.list_idxs = (const int *)(lds + ga.o_lidxs);
     }
     if (ga.lane_walk & 2) lsc = a.sc; /* test knob: every table from HBM */
-    if (threadIdx.x == 0) s_lsc = lsc;
+    if (threadIdx.x == 0) { s_lsc = lsc; cam_view_fill(s_cam, a); }
     __syncthreads();
     const DSphere *spheres = lsc.spheres;
     const DQuad *quads = lsc.quads;
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
 
 #ifdef MORT_PROFILE_STATES
     unsigned long long gp_steps[4] = {0, 0, 0, 0}, gp_lanes[4] = {0, 0, 0, 0}, gp_cyc[5] = {0, 0, 0, 0, 0}, gp_lprims = 0, gp_liters = 0;
-    unsigned long long gp_sp[4] = {0, 0, 0, 0}, gps0 = 0, gps1; /* S parts: shade, finish, new pixel, new ray */
+    unsigned long long gp_sp[6] = {0, 0, 0, 0, 0, 0}, gps0 = 0, gps1; /* S parts: stack store, finish, new pixel, new ray, decode, shade call */
     unsigned long long gpt0 = __builtin_readcyclecounter(), gpt1;
 #define GPROFS0() do { gps0 = __builtin_readcyclecounter(); } while (0)
 #define GPROFS(i) do { gps1 = __builtin_readcyclecounter(); gp_sp[i] += gps1 - gps0; gps0 = gps1; } while (0)
@@ -255,6 +256,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         kind = K_FINISH;
                     } else {
                         const Best b = gen_decode_best(lsc, chains, best, closest);
+                        GPROFS(4);
 #ifdef MORT_DEBUG_PRINT
                         if (lofs == a.debug_lofs) printf("   decode: kind %d prim %d chain %d+%d t %.9g | chains[0..3] %d %d %d %d o_chains %u\n", b.kind, b.prim, b.chain_first, b.chain_count, b.t,
                             chains[0], chains[1], chains[2], chains[3], ga.o_chains);
@@ -270,6 +272,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
 #ifdef MORT_DEBUG_PRINT
                         if (lofs == a.debug_lofs) printf("   shaded: done %d ident %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", (int)so.done, (int)so.ident, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
 #endif
+                        GPROFS(5);
                         if (so.done) { final_value = so.final_value; kind = K_FINISH; }
                         else {
                             if (so.ident) ident_mask |= (1ull << iter);
@@ -346,7 +349,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                 GPROFS(2);
                 if (state != G_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
-                        ray = get_ray(a, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
+                        ray = get_ray(s_cam, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
                         ray_time0 = ray.tm;
                         iter = 0;
                         kind = K_SHADE;
@@ -396,7 +399,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
         for (int k = 0; k < 4; k++) { atomicAdd(&a.counters[4 + 2 * k], gp_steps[k]); atomicAdd(&a.counters[5 + 2 * k], gp_lanes[k]); }
         for (int k = 0; k < 5; k++) atomicAdd(&a.counters[12 + k], gp_cyc[k]);
         atomicAdd(&a.counters[17], gp_liters); atomicAdd(&a.counters[18], gp_lprims);
-        for (int k = 0; k < 4; k++) atomicAdd(&a.counters[20 + k], gp_sp[k]);
+        for (int k = 0; k < 6; k++) atomicAdd(&a.counters[20 + k], gp_sp[k]);
     }
 #endif
 }

@@ -858,8 +858,8 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
                 std::fprintf(stderr, "[gen %s] %12llu wave-steps  lanes %5.1f%%  cycles %5.1f%% (%.0f/step)\n", nm[k], cnt[4 + 2 * k],
                              cnt[4 + 2 * k] ? 100.0 * (double)cnt[5 + 2 * k] / (64.0 * (double)cnt[4 + 2 * k]) : 0.0, 100.0 * (double)cnt[12 + k] / tot,
                              cnt[4 + 2 * k] ? (double)cnt[12 + k] / (double)cnt[4 + 2 * k] : 0.0);
-            std::fprintf(stderr, "[gen S parts, cycles per S step] shade %.0f  finish %.0f  newpix %.0f  newray %.0f\n", (double)cnt[20] / (double)cnt[10], (double)cnt[21] / (double)cnt[10],
-                         (double)cnt[22] / (double)cnt[10], (double)cnt[23] / (double)cnt[10]);
+            std::fprintf(stderr, "[gen S parts, cycles per S step] scan+decode %.0f  shade call %.0f  stack store %.0f  finish %.0f  newpix %.0f  newray %.0f\n", (double)cnt[24] / (double)cnt[10],
+                         (double)cnt[25] / (double)cnt[10], (double)cnt[20] / (double)cnt[10], (double)cnt[21] / (double)cnt[10], (double)cnt[22] / (double)cnt[10], (double)cnt[23] / (double)cnt[10]);
             std::fprintf(stderr, "[gen sched] cycles %5.1f%%; leaf loop: %.2f iterations per L step, %.1f lanes per iteration; scans %llu; steps per segment: T %.2f L %.2f M %.2f S %.2f\n",
                          100.0 * (double)cnt[16] / tot, cnt[6] ? (double)cnt[17] / (double)cnt[6] : 0.0, cnt[17] ? (double)cnt[18] / (double)cnt[17] : 0.0, cnt[3],
                          (double)cnt[5] / (double)(segs + 1), (double)cnt[7] / (double)(segs + 1), (double)cnt[9] / (double)(segs + 1), (double)cnt[11] / (double)(segs + 1));
