@@ -106,7 +106,9 @@ def profile_figures(tag, kernel_substr):
             if kernel_substr in r["kernel"] and "true" not in targs[1:2] + targs[3:4]:  # neither the cost probe nor the non-parity launch
                 c.setdefault(r["counter"], float(r.get("max_dispatch") or r["per_dispatch"]))
         # 1024 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines; a VALU instruction holds its SIMD for 4 cycles
-        out["valu_issue_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0)
+        raw = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0)
+        out["valu_issue_frac"] = min(1.0, raw)  # the two counters come from different passes: a saturated kernel can read a percent above 1
+        out["valu_issue_frac_raw"] = raw
         out["valu_lane_occupancy"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)
         out["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
         out["valu_source"] = (f"profiles/{tag}_pmc_sq_summary.csv: issue = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32); "
