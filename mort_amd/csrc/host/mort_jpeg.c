@@ -88,8 +88,24 @@ static int decode_symbol(bitreader *b, const huff_table *t) {
     return -1;
 }
 
-static const uint8_t zigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                   35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+/* 64 entries + 15: a damaged scan can run a block's coefficient index up to 63 + 15; the reference's decoder lets those land on
+ * coefficient 63 instead of refusing the file (external/stb_image.h:2253-2256 with its padded table), and so does this one */
+static const uint8_t zigzag[64 + 15] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                        35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+                                        63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+/* the two range checks the reference's decoder applies to a block's DC term (external/stb_image.h:2221-2224, 1068-1082): the prediction
+ * must not overflow int, and the dequantised value -- both factors first narrowed to 16 bits -- must stay a short, judged the way that
+ * decoder judges it (it accepts a factor of 0 or -1 outright and compares against the truncated quotient otherwise) */
+static int dc_sum_ok(int pred, int diff) {
+    const long long v = (long long)pred + (long long)diff;
+    return v >= -2147483647LL - 1 && v <= 2147483647LL;
+}
+static int dc_product_ok(short dc, short q) {
+    if (q == 0 || q == -1) return 1;
+    if ((dc >= 0) == (q >= 0)) return dc <= 32767 / q;
+    if (q < 0) return dc <= -32768 / q;
+    return dc >= -32768 / q;
+}
 
 /* 12-bit fixed-point constant of a float literal, rounded as (int)(x * 4096 + 0.5) */
 #define FX(x) ((int)(((x) * 4096 + 0.5)))
@@ -251,15 +267,17 @@ unsigned char *mort_decode_jpeg(const unsigned char *data, size_t size, int *wid
                                 const uint16_t *q = quant[comp[i].tq];
                                 int t = decode_symbol(&br, &hdc[comp[i].td]);
                                 if (t < 0 || t > 15) goto fail;
-                                comp[i].dc_pred += t ? extend(receive(&br, t), t) : 0;
+                                const int diff = t ? extend(receive(&br, t), t) : 0;
+                                if (!dc_sum_ok(comp[i].dc_pred, diff)) goto fail;
+                                comp[i].dc_pred += diff;
+                                if (!dc_product_ok((short)comp[i].dc_pred, (short)q[0])) goto fail;
                                 blk[0] = (short)(comp[i].dc_pred * q[0]);
                                 for (int k = 1; k < 64;) {
                                     const int rs = decode_symbol(&br, &hac[comp[i].ta]);
                                     if (rs < 0) goto fail;
                                     const int r = rs >> 4, s = rs & 15;
                                     if (s == 0) { if (r != 15) break; k += 16; continue; }
-                                    k += r;
-                                    if (k > 63) goto fail;
+                                    k += r; /* <= 63 + 15: the padded table */
                                     const int z = zigzag[k++];
                                     blk[z] = (short)(extend(receive(&br, s), s) * q[z]);
                                 }

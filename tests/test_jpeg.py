@@ -67,3 +67,47 @@ def test_live_reference_decoder_agrees_when_built(tmp_path):
     want = np.load(os.path.join(HERE, "golden", "earthmap_rgb.npz"))["rgb"]
     assert (ref == want).all()
     assert (_decode(os.path.join(HERE, "golden", "earthmap.jpg")) == ref).all()
+
+
+def _stb(exe, path, tmp_path):
+    import subprocess
+    ppm = tmp_path / "stb.ppm"
+    if ppm.exists():
+        ppm.unlink()
+    p = subprocess.run([exe, str(path), str(ppm)], capture_output=True)
+    if p.returncode != 0 or not ppm.exists():
+        return None
+    raw = ppm.read_bytes()
+    hdr = raw[:32].split()
+    w, h = int(hdr[1]), int(hdr[2])
+    off = raw.index(b"255") + 4
+    return np.frombuffer(raw[off:off + w * h * 3], dtype=np.uint8).reshape(h, w, 3)
+
+
+def test_damaged_files_decode_like_the_reference_decoder(tmp_path):
+    """Truncated scans and flipped bytes: whatever the reference's stb_image makes of the file (it pads a short scan with zeros), the
+    product decoder makes the same bytes of it, or both refuse it."""
+    import pytest
+    exe = os.path.join(os.path.dirname(HERE), "oracle", "_ref", "stb_decode")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref not built here (no /root/reference)")
+    data = open(os.path.join(HERE, "golden", "earthmap.jpg"), "rb").read()
+    rng = np.random.default_rng(11)
+    cases = [data[:n] for n in (600, 2000, 20000, len(data) - 1000, len(data) - 3)]
+    for _ in range(60):  # damage inside the entropy-coded scan (headers stay valid)
+        d = bytearray(data)
+        for i in rng.integers(1000, len(d) - 2, size=int(rng.integers(1, 6))):
+            d[int(i)] = int(rng.integers(0, 255))  # never 0xff: no new markers
+        cases.append(bytes(d))
+    compared = 0
+    for k, blob in enumerate(cases):
+        f = tmp_path / f"case{k}.jpg"
+        f.write_bytes(blob)
+        ours, ref = _decode(str(f)), _stb(exe, f, tmp_path)
+        if ref is None:
+            assert ours is None
+            continue
+        assert ours is not None and ours.shape == ref.shape
+        assert (ours == ref).all(), f"case {k}: {int((ours != ref).sum())} bytes differ"
+        compared += 1
+    assert compared >= 5
