@@ -62,7 +62,9 @@ struct __attribute__((aligned(16))) DNode2 {
 #define MORT_OWN_STACK 16 /* pending far children per lane kept in LDS; deeper walks use the reference walk */
 #define MORT_OWN_MAX_DEPTH 15
 /* unified tree (scene_compile.h build_unified): at most this many primitives per leaf; an entry names one primitive */
+#ifndef MORT_GEN_LEAF_MAX
 #define MORT_GEN_LEAF_MAX 4
+#endif
 #define GENT(kind, chain, idx) (((uint32_t)(kind) << 31) | ((uint32_t)(chain) << 24) | (uint32_t)(idx))
 #define GENT_QUAD(e) ((e) >> 31)
 #define GENT_CHAIN(e) (((e) >> 24) & 0x7fu)

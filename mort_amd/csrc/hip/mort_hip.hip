@@ -302,7 +302,10 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
         gb.resize((gb.size() + 15) & ~(size_t)15, 0);
         const size_t lds_part = gb.size();
         const size_t o_ranks = place(gb, o.g_ranks); /* HBM only: read when two hits have equal t */
-        if (lds_part <= 100 * 1024) {
+#ifndef MORT_GEN_IMAGE_MAX
+#define MORT_GEN_IMAGE_MAX (100 * 1024)
+#endif
+        if (lds_part <= MORT_GEN_IMAGE_MAX) {
             HIPCHK(c, hipMalloc(&c->d_gen, gb.size()));
             HIPCHK(c, hipMemcpy(c->d_gen, gb.data(), gb.size(), hipMemcpyHostToDevice));
             c->gen_bytes = (uint32_t)lds_part;
