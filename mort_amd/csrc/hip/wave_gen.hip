@@ -137,6 +137,16 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
             staged[k] = 0; \
         } } while (0)
 
+#ifdef MORT_PROFILE_STATES /* per-state wave-steps, lanes and cycles (scripts/wave_profile.py; printed by mort_hip_render) */
+    unsigned long long pr_steps[3] = {0, 0, 0}, pr_lanes[3] = {0, 0, 0}, pr_cyc[4] = {0, 0, 0, 0};
+    unsigned long long pt0 = __builtin_readcyclecounter(), pt1;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#define WGPROF(i, lanes) do { pr_steps[i] += 1; pr_lanes[i] += (unsigned long long)(lanes); } while (0)
+#define WGPROFC(i) do { pt1 = __builtin_readcyclecounter(); pr_cyc[i] += pt1 - pt0; pt0 = pt1; } while (0)
+#else
+#define WGPROF(i, lanes) do { } while (0)
+#define WGPROFC(i) do { } while (0)
+#endif
     for (;;) {
         const int nT = __popcll(__ballot(state == W_T));
         const int nL = __popcll(__ballot(state == W_L));
@@ -147,10 +157,12 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
         else if (nL >= th_l) pick = W_L;
         else if (nT > 0) pick = W_T;
         else pick = (nL >= nF) ? W_L : W_F;
+        WGPROFC(3);
 
         if (pick == W_T) {
             int keep;
             do {
+                WGPROF(0, __popcll(__ballot(state == W_T)));
                 if (state == W_T) { /* both child boxes of one node (dev_gen.h gen_prune) */
                     const float4 *np = (const float4 *)(nodes2 + node);
                     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
@@ -170,7 +182,9 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
                 }
                 keep = __popcll(__ballot(state == W_T));
             } while (keep >= t_keep);
+            WGPROFC(0);
         } else if (pick == W_L) {
+            WGPROF(1, nL);
             uint32_t lpos = 0;
             int cnt = 0;
             if (state == W_L) { const uint32_t rec = leaves[node]; lpos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
@@ -188,7 +202,9 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
                     state = (next & 0x8000u) ? W_L : W_T;
                 } else state = W_F;
             }
+            WGPROFC(1);
         } else {
+            WGPROF(2, nF);
             /* wave-uniform control flow: every lane runs this block */
             const bool inF = (state == W_F);
             const bool fin = inF && have;
@@ -253,9 +269,18 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
                 b_off += take; served += take;
             }
             if (inF && !have) state = W_DONE; /* this wave's batches are exhausted */
+            WGPROFC(2);
         }
     }
     WG_FLUSH(0); WG_FLUSH(1); WG_FLUSH(2);
+#ifdef MORT_PROFILE_STATES
+    if (lane == 0) {
+        for (int k = 0; k < 3; k++) { atomicAdd(&a.counters[4 + k], pr_steps[k]); atomicAdd(&a.counters[8 + k], pr_lanes[k]); }
+        for (int k = 0; k < 4; k++) atomicAdd(&a.counters[12 + k], pr_cyc[k]);
+        atomicAdd(&a.counters[20], __builtin_amdgcn_s_memrealtime() - rt0); /* sum of wave lifetimes, 10 ns ticks */
+        atomicAdd(&a.counters[21], 1ull);
+    }
+#endif
 #undef WG_FLUSH
 }
 
