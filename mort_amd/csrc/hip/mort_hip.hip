@@ -459,13 +459,14 @@ static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera 
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav, MORT_WF_BLOCK, trav_lds) != hipSuccess || per_cu < 1) per_cu = 1;
     const int max_trav_grid = c->num_cus * per_cu;
+    size_t wf_share = 1; /* 64-record batches per wave at least (MORT_WAVE_SHARE; 2 was 4 % slower: a front's time is its slowest wave's) */
+    { const char *sh = std::getenv("MORT_WAVE_SHARE"); if (sh && std::atoi(sh) >= 1) wf_share = (size_t)std::atoi(sh); }
     const long long max_fronts = (long long)cam->sqrt_spp * cam->sqrt_spp * ((long long)cam->bounce_limit + 1) + 8;
     size_t live = N;
     long long front = 0;
     const int chunk = 32;
     while (live > 0 && front < max_fronts) {
-        /* a wave's slice should hold at least two 64-record batches: fewer, fuller workgroups on small fronts */
-        int tg = (int)((live + (size_t)(MORT_WF_BLOCK / 64) * 128 - 1) / ((size_t)(MORT_WF_BLOCK / 64) * 128));
+        int tg = (int)((live + (size_t)(MORT_WF_BLOCK / 64) * 64 * wf_share - 1) / ((size_t)(MORT_WF_BLOCK / 64) * 64 * wf_share));
         if (tg > max_trav_grid) tg = max_trav_grid;
         if (tg < 1) tg = 1;
         const int sg = (int)((live + 255) / 256) + 3;
