@@ -86,10 +86,17 @@ def host_loop(args, threads):
     return out
 
 
-def profile_figures(tag, kernel_substr):
+def _norm_kernel(name):
+    """'void mega_bvh_kernel<768 false false false>(FastArgs)' and 'mega_bvh_kernel<768, false, false, false>' -> the same key."""
+    return name.replace("void ", "").split("(")[0].replace(",", "").replace(" ", "")
+
+
+def profile_figures(tag, kernel_name, valu_cpi):
     """Counter figures of the profiled configuration, computed from the rocprofv3 summaries committed under
     profiles/ (rocprofv3 cannot run inside this process): HBM traffic per launch, VALU issue fraction and VALU
-    lane occupancy of the dominant kernel."""
+    lane occupancy of the dominant kernel.  `kernel_name` is the launch's own name (template arguments included), so the
+    one-sample cost probe and the non-parity launch of the same template never match.  `valu_cpi`: cycles one SIMD needs per
+    wave64 VALU instruction, measured on this box by mort_hip_calib_valu (the guide's figure is 2)."""
     import csv
     out = {"traffic": None, "config": None}
     try:
@@ -101,18 +108,25 @@ def profile_figures(tag, kernel_substr):
         pass
     try:
         c = {}
+        want = _norm_kernel(kernel_name)
         for r in csv.DictReader(open(os.path.join(ROOT, "profiles", tag + "_pmc_sq_summary.csv"))):
-            targs = [t.strip() for t in r["kernel"].split("<")[-1].split(">")[0].split(",")]  # mega_bvh_kernel<BLOCK, PROBE, DRAIN, SUB>
-            if kernel_substr in r["kernel"] and "true" not in targs[1:2] + targs[3:4]:  # neither the cost probe nor the non-parity launch
-                c.setdefault(r["counter"], float(r.get("max_dispatch") or r["per_dispatch"]))
-        # 1024 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines; a VALU instruction holds its SIMD for 4 cycles
-        raw = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * c["SQ_BUSY_CYCLES"] / 32.0)
-        out["valu_issue_frac"] = min(1.0, raw)  # the two counters come from different passes: a saturated kernel can read a percent above 1
-        out["valu_issue_frac_raw"] = raw
+            if _norm_kernel(r["kernel"]) == want or (kernel_name.startswith("wf_") and "wf_" in r["kernel"]):
+                c[r["counter"]] = c.get(r["counter"], 0.0) + float(r["sum_over_dispatches"] if kernel_name.startswith("wf_") else (r.get("max_dispatch") or r["per_dispatch"]))
+        # 1024 SIMDs; SQ_BUSY_CYCLES is summed over the 32 shader engines.  Issue fraction = VALU instructions x (cycles a SIMD
+        # needs per instruction) / SIMD-cycles of the launch.  No clamp: a value above 1 would mean the model is wrong.
+        simd_cycles = 1024.0 * c["SQ_BUSY_CYCLES"] / 32.0
+        out["valu_issue_frac"] = c["SQ_INSTS_VALU"] * valu_cpi / simd_cycles
+        out["valu_cycles_per_inst_per_simd"] = valu_cpi
         out["valu_lane_occupancy"] = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_INSTS_VALU"] * 64.0)
+        out["valu_lane_throughput_frac"] = out["valu_issue_frac"] * out["valu_lane_occupancy"]
         out["valu_insts_per_launch"] = c["SQ_INSTS_VALU"]
-        out["valu_source"] = (f"profiles/{tag}_pmc_sq_summary.csv: issue = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x SQ_BUSY_CYCLES / 32); "
-                              "lane occupancy = SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64)")
+        if "SQ_INSTS_SALU" in c and "SQ_INSTS_BRANCH" in c:
+            tot = c["SQ_INSTS_VALU"] + c["SQ_INSTS_SALU"] + c["SQ_INSTS_BRANCH"] + c.get("SQ_INSTS_LDS", 0) + c.get("SQ_INSTS_FLAT", 0) + c.get("SQ_INSTS_SMEM", 0)
+            out["scalar_and_branch_share_of_insts"] = (c["SQ_INSTS_SALU"] + c["SQ_INSTS_BRANCH"]) / tot
+        if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+            out["wave_wait_share"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+        out["valu_source"] = (f"profiles/{tag}_pmc_sq_summary.csv: issue = SQ_INSTS_VALU x {valu_cpi:.2f} cycles (measured, mort_hip_calib_valu) / "
+                              "(1024 SIMDs x SQ_BUSY_CYCLES / 32); lane occupancy = SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64)")
     except Exception:
         pass
     return out
@@ -136,6 +150,7 @@ def main():
     ap.add_argument("--mode", choices=["mega", "wave", "throughput"], default="mega",
                     help="mega: the headline megakernel; wave: the wavefront (HBM-streaming) form of the same path; throughput: the labelled "
                          "NON-PARITY mode (one stream per (pixel, stratum row) -- other random numbers than the reference's; never the headline)")
+    ap.add_argument("--no-calib", action="store_true", help="skip the roofline calibration kernels (profiling runs: keeps the kernel list to the render's)")
     ap.add_argument("--no-throughput-line", action="store_true", help="skip the extra non-parity figure (profiling runs: keeps the kernel list to the headline's)")
     args = ap.parse_args()
 
@@ -267,10 +282,21 @@ def main():
             algo_bytes = int(st["algorithmic_hbm_bytes"])  # + 240 B per segment of front / hit / pixel / stack records (wave_bvh.h)
         achieved = algo_bytes / avg_kernel_s / 1e9 if avg_kernel_s > 0 else 0.0
         kernel_name = ("wf_trav + wf_shade (per front)" if args.mode == "wave" else st["kernel_name"])
+        # roofline calibration on THIS box, outside the timed region (include/mort_hip.h mort_hip_calib_*): the HBM rate a float4
+        # copy reaches, and the cycles a SIMD needs per wave64 VALU instruction at 1, 3 and 8 resident waves
+        calib = None
+        if world_size == 1 and not args.no_calib:
+            cv = {w: ctx.calib_valu(w, 0)["cycles_per_valu_per_simd"] for w in (1, 3, 8)}
+            calib = {"hbm_copy_GBs": ctx.calib_hbm_copy(1 << 30, 3), "valu_cycles_per_inst_per_simd": {str(w): v for w, v in cv.items()},
+                     "note": "mort_hip_calib_valu (independent v_fma_f32, waves per SIMD -> cycles per instruction per SIMD) and "
+                             "mort_hip_calib_hbm_copy (float4 copy of 1 GiB per buffer, read + write)"}
+        valu_cpi = min(calib["valu_cycles_per_inst_per_simd"].values()) if calib else 2.0  # MI355X_MICROARCH.md: 2 cycles (SIMD-32)
         # counter figures from the PMC passes committed under profiles/, quoted only when this run is the profiled configuration
-        pf = profile_figures(args.profile_tag, "wf_" if args.mode == "wave" else kernel_name.split("<")[0])
+        pf = profile_figures(args.profile_tag, "wf_" if args.mode == "wave" else kernel_name, valu_cpi)
         cfg = pf.get("config") or {}
-        same = (args.scene, W, args.spp, world_size, args.mode) == (cfg.get("scene"), cfg.get("width"), cfg.get("spp"), cfg.get("gpus"), cfg.get("mode", "mega"))
+        same = (args.scene, W, H, args.spp, cam.bounce_limit, world_size, args.mode) == (
+            cfg.get("scene"), cfg.get("width"), cfg.get("height", H if args.aspect is None else None), cfg.get("spp"),
+            cfg.get("depth", cam.bounce_limit if args.depth is None else None), cfg.get("gpus"), cfg.get("mode", "mega"))
         if not same:
             pf = {"traffic": None}
         traffic = pf.get("traffic")
@@ -286,18 +312,23 @@ def main():
                        "nominal_msamples_per_s": W * H * args.spp * args.steps / elapsed_max / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "peak_measured": calib["hbm_copy_GBs"] if calib else None,
                          "kernel": kernel_name,
                          "avg_kernel_ms": avg_kernel_s * 1e3,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "traffic_source": pf.get("traffic_source"),
                          "note": ("megakernel keeps scene, RNG state and bounce stack on chip: 0 B/segment by construction, "
-                                  "so the HBM fraction is tiny; the binding resource is VALU issue (DESIGN.md 4)") if args.mode == "mega" else
+                                  "so the HBM fraction is tiny; what binds it is instruction latency at the occupancy its registers allow -- "
+                                  "valu_issue_frac x valu_lane_occupancy is the share of the VALU lane throughput it uses (DESIGN.md 4.7)") if args.mode == "mega" else
                                  ("NON-PARITY mode: one stream per (pixel, stratum row), so a pixel's sqrt_spp rows are independent work items; results are "
                                   "this mode's own (tests/test_gpu_throughput.py), not the reference's -- reported beside the headline, never as it") if args.mode == "throughput" else
                                  ("wavefront form: 100 B per pixel + 240 B per segment of front / hit / pixel / stack records; bound by "
                                   "front granularity (one segment of every live pixel per launch pair), not by HBM (DESIGN.md 4)"),
                          "valu_issue_frac": pf.get("valu_issue_frac"), "valu_lane_occupancy": pf.get("valu_lane_occupancy"),
+                         "valu_lane_throughput_frac": pf.get("valu_lane_throughput_frac"),
+                         "scalar_and_branch_share_of_insts": pf.get("scalar_and_branch_share_of_insts"), "wave_wait_share": pf.get("wave_wait_share"),
                          "valu_insts_per_launch": pf.get("valu_insts_per_launch"), "valu_source": pf.get("valu_source")},
+            "calibration": calib,
             "kernel": {"segments_per_frame": st["segments"], "segments_per_s": st["segments"] / st["seconds"],
                        "hip_event_seconds": st["seconds"], "vgprs": st["kernel_vgprs"], "lds_bytes": st["kernel_lds_bytes"]},
         }

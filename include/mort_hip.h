@@ -143,6 +143,22 @@ int mort_hip_render_gather(mort_ctx *ctx, const mort_camera *cam, int mode, uint
 /* One-rank rehearsal of the RCCL path (library load, communicator, grouped send / recv to self, de-interleave): MORT_OK when the bytes come back. */
 int mort_hip_comm_selftest(mort_ctx *ctx);
 
+/* ---- roofline calibration (measurement only; bench.py prints the results beside the render kernels' counters).
+ * mort_hip_calib_valu: shader cycles one SIMD needs per wave64 VALU instruction with exactly `waves_per_simd` (1..8) waves
+ * resident on every SIMD; kind 0 = independent v_fma_f32, 1 = one dependent v_fma_f32 chain, 2 = independent v_fma_f64,
+ * 3 = three v_fma_f32 per scalar instruction.  mort_hip_calib_hbm_copy: GB/s (read + write) of a float4 copy of `bytes`
+ * per buffer (use > 256 MB, the Infinity Cache), best of `reps`. ---- */
+typedef struct mort_calib_valu {
+    int waves_per_simd, kind;
+    double seconds;                  /* HIP-event time of the launch */
+    double cycles_per_wave;          /* s_memtime ticks around the loop, median over waves */
+    double clock_ghz;                /* s_memtime ticks per s_memrealtime tick (100 MHz), median over waves */
+    double valu_per_wave;            /* VALU instructions each wave issued */
+    double cycles_per_valu_per_simd; /* cycles_per_wave / (valu_per_wave * waves_per_simd) */
+} mort_calib_valu;
+int mort_hip_calib_valu(mort_ctx *ctx, int waves_per_simd, int kind, mort_calib_valu *out);
+int mort_hip_calib_hbm_copy(mort_ctx *ctx, size_t bytes, int reps, double *gbs_out);
+
 /* Number of rows owned for an image of `height` rows under the current partition. */
 int mort_hip_local_rows(const mort_ctx *ctx, int height);
 /* Global row index of local row `local_row`. */

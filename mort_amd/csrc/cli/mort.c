@@ -23,7 +23,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <signal.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
@@ -31,9 +33,22 @@
 #include "mort_hip.h"
 #include "mort_host.h"
 
+/* ---- `--gpus N`: no rank may outlive a failed peer.  The frame gather is collective (rank 0 blocks in ncclRecv + a stream wait, the
+ * peers in ncclSend), so a rank that fails takes the others down instead of leaving them waiting: a forked rank signals rank 0
+ * (SIGUSR1), whose handler kills every rank and exits non-zero; rank 0 kills its ranks before it exits itself; and every forked rank
+ * asks the kernel for SIGKILL when rank 0 dies for any other reason (PR_SET_PDEATHSIG). ---- */
+static pid_t g_kids[64];
+static int g_nkids = 0, g_rank = 0;
+static void kill_ranks(void) { for (int r = 1; r <= g_nkids; r++) if (g_kids[r] > 0) kill(g_kids[r], SIGKILL); }
+static void on_rank_failed(int sig) { (void)sig; kill_ranks(); static const char m[] = "a rank failed\n"; if (write(2, m, sizeof m - 1) < 0) { } _exit(EXIT_FAILURE); }
+static void fail_exit(void) {
+    if (g_rank == 0) kill_ranks();
+    else kill(getppid(), SIGUSR1);
+    exit(EXIT_FAILURE);
+}
 static void die(mort_ctx *ctx, int st, const char *what) {
     fprintf(stderr, "%s: %s %s\n", what, mort_hip_strerror(st), ctx ? mort_hip_last_error(ctx) : "");
-    exit(EXIT_FAILURE);
+    fail_exit();
 }
 static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; }
 
@@ -159,18 +174,32 @@ int main(int argc, char **argv) {
             if (shm == MAP_FAILED) { perror("mmap"); return EXIT_FAILURE; }
         }
         for (int r = 1; r < gpus; r++) if (pipe(id_pipe[r]) != 0) { perror("pipe"); return EXIT_FAILURE; }
+        signal(SIGUSR1, on_rank_failed);
+        const pid_t parent = getpid();
         for (int r = 1; r < gpus; r++) {
             pid_t p = fork();
-            if (p < 0) { perror("fork"); return EXIT_FAILURE; }
-            if (p == 0) { rank = r; break; }
-            kids[r] = p;
+            if (p < 0) { perror("fork"); kill_ranks(); return EXIT_FAILURE; }
+            if (p == 0) {
+                rank = g_rank = r; g_nkids = 0;
+                signal(SIGUSR1, SIG_DFL);
+                prctl(PR_SET_PDEATHSIG, SIGKILL);
+                if (getppid() != parent) _exit(EXIT_FAILURE); /* rank 0 died before the request took effect */
+                break;
+            }
+            kids[r] = g_kids[r] = p; g_nkids = r;
         }
         device = n_devices ? devices[rank] : rank;
+        /* test hooks for the failure path (tests/test_cli.py; no GPU needed): MORT_TEST_FAIL_RANK=r makes rank r fail here,
+         * MORT_TEST_BLOCK_RANK0=1 makes rank 0 wait as it would inside the gather */
+        const char *tf = getenv("MORT_TEST_FAIL_RANK");
+        if (tf && atoi(tf) == rank) { if (rank > 0) usleep(200000); fprintf(stderr, "rank %d: MORT_TEST_FAIL_RANK\n", rank); fail_exit(); }
+        if (tf && rank == 0 && getenv("MORT_TEST_BLOCK_RANK0")) { sleep(60); fprintf(stderr, "rank 0 was not taken down by the failed rank\n"); kill_ranks(); return 3; }
+        if (tf && rank != 0) { sleep(60); _exit(3); } /* a healthy peer that would wait in ncclSend: must be killed, not waited for */
     }
 
     uint8_t *rgba = calloc(npx, 4);
     float *accum = dump ? calloc(npx * 3, sizeof(float)) : NULL;
-    if (!rgba || (dump && !accum)) { fprintf(stderr, "out of memory\n"); return EXIT_FAILURE; }
+    if (!rgba || (dump && !accum)) { fprintf(stderr, "out of memory\n"); fail_exit(); }
     mort_stats stats;
     memset(&stats, 0, sizeof stats);
     double total_ms = 0, frame_wall = 0;
@@ -203,8 +232,8 @@ int main(int argc, char **argv) {
                 unsigned char id[MORT_COMM_ID_BYTES];
                 if (rank == 0) {
                     if ((st = mort_hip_comm_id(id)) != MORT_OK) die(ctx, st, "mort_hip_comm_id");
-                    for (int r = 1; r < gpus; r++) if (write(id_pipe[r][1], id, sizeof id) != (ssize_t)sizeof id) { perror("write"); return EXIT_FAILURE; }
-                } else if (read(id_pipe[rank][0], id, sizeof id) != (ssize_t)sizeof id) { perror("read"); return EXIT_FAILURE; }
+                    for (int r = 1; r < gpus; r++) if (write(id_pipe[r][1], id, sizeof id) != (ssize_t)sizeof id) { perror("write"); fail_exit(); }
+                } else if (read(id_pipe[rank][0], id, sizeof id) != (ssize_t)sizeof id) { perror("read"); fail_exit(); }
                 if ((st = mort_hip_comm_init(ctx, id, rank, gpus)) != MORT_OK) die(ctx, st, "mort_hip_comm_init");
             }
         }
@@ -212,7 +241,7 @@ int main(int argc, char **argv) {
         if (sin) {
             mort_rng_state *s = malloc(npx * sizeof *s);
             FILE *f = fopen(sin, "rb");
-            if (!s || !f || fread(s, sizeof *s, npx, f) != npx) { fprintf(stderr, "cannot read %zu states from %s\n", npx, sin); return EXIT_FAILURE; }
+            if (!s || !f || fread(s, sizeof *s, npx, f) != npx) { fprintf(stderr, "cannot read %zu states from %s\n", npx, sin); fail_exit(); }
             fclose(f);
             if ((st = mort_hip_rng_load(ctx, s, W, H)) != MORT_OK) die(ctx, st, "mort_hip_rng_load");
             free(s);
@@ -243,7 +272,7 @@ int main(int argc, char **argv) {
     }
     int failed = 0;
     for (int r = 1; r < gpus; r++) { int ws = 0; if (waitpid(kids[r], &ws, 0) < 0 || !WIFEXITED(ws) || WEXITSTATUS(ws) != 0) failed = 1; }
-    if (failed) { fprintf(stderr, "a rank failed\n"); return EXIT_FAILURE; }
+    if (failed) { fprintf(stderr, "a rank failed\n"); kill_ranks(); return EXIT_FAILURE; }
     if (gpus > 1 && gather_shm) {
         const int lr = mort_hip_local_rows(ctx, H); /* rank 0's own rows are already in rgba; take the others from the mapping */
         uint8_t *own = malloc(npx * 4);

@@ -106,6 +106,11 @@ extern "C" void mort_hip_comm_destroy(mort_ctx *c) {
     if (c) { hipFree(c->d_gather); hipFree(c->d_frame); c->d_gather = c->d_frame = nullptr; c->gather_cap = c->frame_cap = 0; }
 }
 
+/* render + gather as ONE stream of work: render kernel(s) -> send / recv group -> de-interleave -> copy out, all enqueued on the
+ * context's stream, one host wait at the end (the render's statistics are collected after it).  Failure discipline (the
+ * exchange is collective): everything that can fail locally -- argument checks, allocations -- happens BEFORE the render; once the
+ * send / recv group is entered it is always closed (GroupEnd), and a rank whose render failed still takes part in the exchange
+ * (its rows are whatever its buffer holds) and reports its error afterwards, so that no peer is left waiting in ncclRecv. */
 extern "C" int mort_hip_render_gather(mort_ctx *c, const mort_camera *cam, int mode, uint8_t *rgba_out, mort_stats *stats) {
     if (!c || !cam) return MORT_ERR_INVALID;
     const int W = cam->image_width, H = cam->image_height;
@@ -117,54 +122,75 @@ extern "C" int mort_hip_render_gather(mort_ctx *c, const mort_camera *cam, int m
     const int lr = rows_of(R, N, rpb, H);
     const size_t max_rows = (size_t)(((H + rpb - 1) / rpb + N - 1) / N) * (size_t)rpb; /* every rank's tile fits */
     const size_t tile_px = max_rows * (size_t)W;
+    /* ---- every allocation first ---- */
     if (c->rgba_cap < tile_px * 4) {
         if (c->d_rgba) { hipFree(c->d_rgba); c->d_rgba = nullptr; c->rgba_cap = 0; }
         HIPCHK(c, hipMalloc(&c->d_rgba, tile_px * 4));
         c->rgba_cap = tile_px * 4;
     }
+    if (N > 1 && R == 0) {
+        if (c->gather_cap < tile_px * 4 * (size_t)N) {
+            hipFree(c->d_gather); c->d_gather = nullptr; c->gather_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_gather, tile_px * 4 * (size_t)N));
+            c->gather_cap = tile_px * 4 * (size_t)N;
+        }
+        if (c->frame_cap < (size_t)W * H * 4) {
+            hipFree(c->d_frame); c->d_frame = nullptr; c->frame_cap = 0;
+            HIPCHK(c, hipMalloc(&c->d_frame, (size_t)W * H * 4));
+            c->frame_cap = (size_t)W * H * 4;
+        }
+    }
+    if (!c->ev_g0) HIPCHK(c, hipEventCreate(&c->ev_g0));
+    if (!c->ev_g1) HIPCHK(c, hipEventCreate(&c->ev_g1));
+    /* ---- render: enqueued, not waited for ---- */
     mort_stats local;
-    int st = mort_hip_render_device(c, cam, mode, c->d_rgba, nullptr, c->stream, &local); /* blocking: stats carry the kernel time */
-    if (st != MORT_OK) return st;
-    hipEvent_t e0 = c->ev0, e1 = c->ev1;
-    HIPCHK(c, hipEventRecord(e0, c->stream));
+    std::memset(&local, 0, sizeof local);
+    c->defer_stats = true; c->pending_stats = nullptr;
+    const int st_render = mort_hip_render_device(c, cam, mode, c->d_rgba, nullptr, c->stream, &local);
+    c->defer_stats = false;
+    /* ---- the exchange: entered by every rank whatever its render returned ---- */
+    int st_x = MORT_OK;
+    ncclResult_t e_x = ncclSuccess;
+    hipError_t h_x = hipEventRecord(c->ev_g0, c->stream);
     if (N == 1) {
-        HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_rgba, (size_t)W * H * 4, hipMemcpyDeviceToHost, c->stream));
+        if (st_render == MORT_OK && h_x == hipSuccess) h_x = hipMemcpyAsync(rgba_out, c->d_rgba, (size_t)W * H * 4, hipMemcpyDeviceToHost, c->stream);
     } else {
-        if (R == 0) {
-            if (c->gather_cap < tile_px * 4 * (size_t)N) {
-                hipFree(c->d_gather); c->d_gather = nullptr; c->gather_cap = 0;
-                HIPCHK(c, hipMalloc(&c->d_gather, tile_px * 4 * (size_t)N));
-                c->gather_cap = tile_px * 4 * (size_t)N;
+        if (R == 0 && h_x == hipSuccess) h_x = hipMemcpyAsync(c->d_gather, c->d_rgba, (size_t)lr * W * 4, hipMemcpyDeviceToDevice, c->stream);
+        e_x = rccl().GroupStart();
+        if (e_x == ncclSuccess) {
+            if (R == 0) {
+                for (int r = 1; r < N && e_x == ncclSuccess; r++) {
+                    const size_t bytes = (size_t)rows_of(r, N, rpb, H) * (size_t)W * 4;
+                    if (bytes) e_x = rccl().Recv((unsigned char *)c->d_gather + (size_t)r * tile_px * 4, bytes, ncclUint8, r, (ncclComm_t)c->comm, c->stream);
+                }
+            } else if (lr > 0) {
+                e_x = rccl().Send(c->d_rgba, (size_t)lr * (size_t)W * 4, ncclUint8, 0, (ncclComm_t)c->comm, c->stream);
             }
-            if (c->frame_cap < (size_t)W * H * 4) {
-                hipFree(c->d_frame); c->d_frame = nullptr; c->frame_cap = 0;
-                HIPCHK(c, hipMalloc(&c->d_frame, (size_t)W * H * 4));
-                c->frame_cap = (size_t)W * H * 4;
-            }
-            HIPCHK(c, hipMemcpyAsync(c->d_gather, c->d_rgba, (size_t)lr * W * 4, hipMemcpyDeviceToDevice, c->stream));
+            const ncclResult_t e_end = rccl().GroupEnd(); /* always closed: a failed Send / Recv must not leave the group open for the next call */
+            if (e_x == ncclSuccess) e_x = e_end;
         }
-        RCHK(c, rccl().GroupStart());
-        if (R == 0) {
-            for (int r = 1; r < N; r++) {
-                const size_t bytes = (size_t)rows_of(r, N, rpb, H) * (size_t)W * 4;
-                if (bytes) RCHK(c, rccl().Recv((unsigned char *)c->d_gather + (size_t)r * tile_px * 4, bytes, ncclUint8, r, (ncclComm_t)c->comm, c->stream));
-            }
-        } else if (lr > 0) {
-            RCHK(c, rccl().Send(c->d_rgba, (size_t)lr * (size_t)W * 4, ncclUint8, 0, (ncclComm_t)c->comm, c->stream));
-        }
-        RCHK(c, rccl().GroupEnd());
-        if (R == 0) {
+        if (R == 0 && e_x == ncclSuccess && h_x == hipSuccess) {
             const size_t npx = (size_t)W * (size_t)H;
             hipLaunchKernelGGL(deinterleave_kernel, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, c->stream, (const uchar4 *)c->d_gather, (uchar4 *)c->d_frame,
                                W, H, N, rpb, tile_px);
-            HIPCHK(c, hipGetLastError());
-            HIPCHK(c, hipMemcpyAsync(rgba_out, c->d_frame, npx * 4, hipMemcpyDeviceToHost, c->stream));
+            h_x = hipGetLastError();
+            if (h_x == hipSuccess) h_x = hipMemcpyAsync(rgba_out, c->d_frame, npx * 4, hipMemcpyDeviceToHost, c->stream);
         }
     }
-    HIPCHK(c, hipEventRecord(e1, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (h_x == hipSuccess) h_x = hipEventRecord(c->ev_g1, c->stream);
+    const hipError_t h_sync = hipStreamSynchronize(c->stream); /* the one host wait */
+    if (e_x != ncclSuccess) st_x = rccl_fail(c, e_x, "frame gather (ncclSend / ncclRecv group)");
+    else if (h_x != hipSuccess) st_x = hip_fail(c, h_x, "frame gather");
+    else if (h_sync != hipSuccess) st_x = hip_fail(c, h_sync, "hipStreamSynchronize(frame gather)");
+    if (st_render != MORT_OK) { c->pending_stats = nullptr; return st_render; }
+    if (st_x != MORT_OK) { c->pending_stats = nullptr; return st_x; }
+    if (c->pending_stats) {
+        const int st_s = c->pending_stats(&local);
+        c->pending_stats = nullptr;
+        if (st_s != MORT_OK) return st_s;
+    }
     float ms = 0;
-    HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_g0, c->ev_g1));
     local.gather_seconds = ms * 1e-3;
     if (stats) *stats = local;
     return MORT_OK;

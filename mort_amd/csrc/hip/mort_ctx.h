@@ -6,6 +6,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -77,6 +78,10 @@ struct mort_ctx {
     void *d_gather = nullptr;        /* rank 0: nranks x max tile bytes */
     void *d_frame = nullptr;         /* rank 0: the de-interleaved W x H x 4 frame */
     size_t gather_cap = 0, frame_cap = 0;
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr; /* brackets of the gather step (created on first use) */
+    /* mort_hip_render_gather: the render's statistics are collected after the gather's one host wait */
+    bool defer_stats = false;
+    std::function<int(mort_stats *)> pending_stats;
 };
 
 static inline int hip_fail(mort_ctx *c, hipError_t e, const char *what) {

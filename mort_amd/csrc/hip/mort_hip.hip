@@ -243,6 +243,11 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, quiesce(c));
     c->cost_key = 0; c->world_serial++;
+    /* nothing of the previous world survives a failed upload: a later render must see MORT_ERR_NO_WORLD, not the old world's
+     * trees walked against the new scene tables */
+    c->have_world = c->fast_ok = c->gen_ok = c->wave_ok = false;
+    if (c->d_fast) { hipFree(c->d_fast); c->d_fast = nullptr; }
+    if (c->d_gen) { hipFree(c->d_gen); c->d_gen = nullptr; }
     int st;
     SceneBlob sb;
     st = build_scene_blob(w, sb);
@@ -260,8 +265,6 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     c->n_wspheres = (int)o.wspheres.size(); c->n_wquads = (int)o.wquads.size(); c->n_lists = w->objs.num_hittable_list;
     /* the LDS kernels handle: one BVH over spheres as the whole world */
     c->wave_ok = (o.items.size() == 1 && o.items[0].kind == ITEM_BVH && o.quads.empty());
-    c->fast_ok = false;
-    if (c->d_fast) { hipFree(c->d_fast); c->d_fast = nullptr; }
     if (c->wave_ok && !o.own_nodes.empty()) {
         std::vector<unsigned char> fb;
         c->f_nodes2 = (uint32_t)place(fb, o.own_nodes); c->f_leaves = (uint32_t)place(fb, o.own_leaves);
@@ -279,8 +282,6 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
         }
     }
     /* unified-tree megakernel: LDS image = tree + every small table (+ the primitives when they fit) */
-    c->gen_ok = false;
-    if (c->d_gen) { hipFree(c->d_gen); c->d_gen = nullptr; }
     if (o.g_ok && !std::getenv("MORT_NO_GEN")) {
         std::vector<unsigned char> gb;
         GenArgs g;
@@ -737,7 +738,9 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         const uint32_t stack_off = tstack_off + (uint32_t)MORT_OWN_STACK * (uint32_t)FB * 2u;
         fa.off_tstack = tstack_off;
         const int groups_per_cu = 768 / FB; /* keep 12 waves per CU */
-        int dl = (int)(((160u * 1024u - 256u) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
+        uint32_t static_lds = 256; /* the kernel's own __shared__ objects come out of the same 160 KB */
+        { hipFuncAttributes fattr; if (hipFuncGetAttributes(&fattr, (const void *)kern) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 255) & ~(size_t)255); }
+        int dl = (int)(((160u * 1024u - static_lds) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
         if (dl > 12) dl = 12;
         if (dl < 0) dl = 0;
         fa.off_stack = stack_off; fa.stack_lds_depth = dl;
@@ -799,7 +802,9 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         const uint32_t stack_off = tstack_off + (uint32_t)MORT_OWN_STACK * (uint32_t)FB * 2u;
         fa.off_tstack = tstack_off;
         const int groups_per_cu = FB == 512 ? 1 : 768 / FB;
-        int dl = (int)(((160u * 1024u - 256u) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
+        uint32_t static_lds = 512; /* the kernel's own __shared__ objects come out of the same 160 KB */
+        { hipFuncAttributes fattr; if (mort_gen_attributes(FB, ga.prims_in_lds != 0, &fattr, substream) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 255) & ~(size_t)255); }
+        int dl = (int)(((160u * 1024u - static_lds) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
         if (dl > 12) dl = 12;
         if (dl < 0) dl = 0;
         { const char *de = std::getenv("MORT_GEN_DL"); if (de && std::atoi(de) < dl) dl = std::atoi(de); }
@@ -837,6 +842,12 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
     }
     if (stats) {
         HIPCHK(c, hipEventRecord(c->ev1, s));
+        /* what the statistics need, by value: mort_hip_render_gather lets the frame gather follow the render on the stream
+         * and collects them after its one wait (c->defer_stats) */
+        const int sqrt_spp_ = cam->sqrt_spp, local_rows_ = a.local_rows;
+        const bool has_accum_ = d_accum != nullptr;
+        const std::string kname_ = kname;
+        auto fill = [=](mort_stats *stats) -> int {
         HIPCHK(c, hipEventSynchronize(c->ev1));
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -894,13 +905,13 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         stats->segments = cnt[0];
         stats->rng_draws = cnt[1];
         stats->reference_walks = ((use_fast || use_gen) && mode != MORT_MODE_WAVE) ? cnt[3] : 0;
-        stats->pixels = (uint64_t)W * (uint64_t)a.local_rows;
-        stats->eff_samples = stats->pixels * (uint64_t)(cam->sqrt_spp * cam->sqrt_spp);
-        stats->algorithmic_hbm_bytes = stats->pixels * (uint64_t)(100 + (d_accum ? 12 : 0));
+        stats->pixels = (uint64_t)W * (uint64_t)local_rows_;
+        stats->eff_samples = stats->pixels * (uint64_t)(sqrt_spp_ * sqrt_spp_);
+        stats->algorithmic_hbm_bytes = stats->pixels * (uint64_t)(100 + (has_accum_ ? 12 : 0));
         stats->scene_in_lds = (use_fast || use_gen || mode == MORT_MODE_WAVE) ? 1 : 0;
         if (mode == MORT_MODE_WAVE) stats->algorithmic_hbm_bytes += 240ull * stats->segments; /* wave_bvh.h: per-segment record traffic */
-        stats->local_rows = a.local_rows;
-        std::memcpy(stats->kernel_name, kname, sizeof stats->kernel_name);
+        stats->local_rows = local_rows_;
+        std::snprintf(stats->kernel_name, sizeof stats->kernel_name, "%s", kname_.c_str());
         hipFuncAttributes fattr;
         const void *kf = (mode == MORT_MODE_WAVE && wave_gen) ? mort_wave_gen_trav_kernel(c->gen.prims_in_lds != 0, nullptr)
                          : mode == MORT_MODE_WAVE ? (const void *)wf_trav<MORT_WF_BLOCK> : !use_fast ? (const void *)mega_kernel
@@ -910,6 +921,10 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             stats->kernel_vgprs = fattr.numRegs;
             stats->kernel_lds_bytes = (use_fast || gen_ran) ? lds_bytes_used : (int)fattr.sharedSizeBytes;
         }
+            return MORT_OK;
+        };
+        if (c->defer_stats) { c->pending_stats = fill; return MORT_OK; }
+        return fill(stats);
     }
     return MORT_OK;
 }

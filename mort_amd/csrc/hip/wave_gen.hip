@@ -483,6 +483,11 @@ hipError_t mort_wave_gen_render(const GenArgs &ga, const WfGenHost &hb, int boun
     w.g.f.off_tstack = (ga.f.hot_bytes + 15u) & ~15u;
     w.t_stage = w.g.f.off_tstack + (uint32_t)MORT_OWN_STACK * (uint32_t)TB * 2u;
     const size_t trav_lds = (size_t)w.t_stage + (size_t)(TB / 64) * 3 * WG_STAGE * sizeof(unsigned);
+    { /* dynamic + the kernel's own __shared__ objects must fit the CU's 160 KB: refuse here rather than fail at the first launch */
+        hipFuncAttributes fattr;
+        WCHK(hipFuncGetAttributes(&fattr, (const void *)trav));
+        if (trav_lds + fattr.sharedSizeBytes > (size_t)160 * 1024) return hipErrorInvalidValue;
+    }
     WCHK(hipFuncSetAttribute((const void *)trav, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trav_lds));
     int per_cu = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trav, TB, trav_lds) != hipSuccess || per_cu < 1) per_cu = 1;

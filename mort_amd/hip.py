@@ -26,6 +26,7 @@ EXPORTS = [
     "mort_hip_set_partition", "mort_hip_rng_seed", "mort_hip_rng_load", "mort_hip_rng_store", "mort_hip_render",
     "mort_hip_render_device", "mort_hip_local_rows", "mort_hip_global_row", "mort_hip_rng_seed_host", "mort_hip_render_host",
     "mort_hip_comm_id", "mort_hip_comm_init", "mort_hip_comm_destroy", "mort_hip_render_gather", "mort_hip_comm_selftest",
+    "mort_hip_calib_valu", "mort_hip_calib_hbm_copy",
 ]
 HOST_TREE = 1
 
@@ -44,6 +45,11 @@ class Stats(C.Structure):
         d = {k: getattr(self, k) for k, _ in self._fields_}
         d["kernel_name"] = d["kernel_name"].decode()
         return d
+
+
+class CalibValu(C.Structure):
+    _fields_ = [("waves_per_simd", C.c_int), ("kind", C.c_int), ("seconds", C.c_double), ("cycles_per_wave", C.c_double),
+                ("clock_ghz", C.c_double), ("valu_per_wave", C.c_double), ("cycles_per_valu_per_simd", C.c_double)]
 
 
 class MortHipError(RuntimeError):
@@ -81,6 +87,8 @@ def lib():
         L.mort_hip_render_host.argtypes = [C.POINTER(S.World), C.POINTER(S.Camera), C.c_void_p, C.c_int, C.c_int, C.c_void_p,
                                            C.c_void_p, C.c_void_p, C.POINTER(Stats)]
         L.mort_hip_render_host.restype = C.c_int
+        L.mort_hip_calib_valu.argtypes = [ctx, C.c_int, C.c_int, C.POINTER(CalibValu)]; L.mort_hip_calib_valu.restype = C.c_int
+        L.mort_hip_calib_hbm_copy.argtypes = [ctx, C.c_size_t, C.c_int, C.POINTER(C.c_double)]; L.mort_hip_calib_hbm_copy.restype = C.c_int
         _lib = L
     return _lib
 
@@ -153,6 +161,18 @@ class Context:
         self._chk(lib().mort_hip_render_device(self._h, C.byref(cam), mode, d_rgba, d_accum or None, stream or None,
                                                C.byref(st) if sync else None), "mort_hip_render_device")
         return st.asdict() if sync else None
+
+    def calib_valu(self, waves_per_simd, kind=0):
+        """Shader cycles one SIMD needs per wave64 VALU instruction at `waves_per_simd` resident waves (include/mort_hip.h)."""
+        r = CalibValu()
+        self._chk(lib().mort_hip_calib_valu(self._h, waves_per_simd, kind, C.byref(r)), "mort_hip_calib_valu")
+        return {k: getattr(r, k) for k, _ in r._fields_}
+
+    def calib_hbm_copy(self, nbytes=1 << 30, reps=3):
+        """GB/s (read + write) of a float4 copy of `nbytes` per buffer: the HBM rate this box reaches."""
+        g = C.c_double(0)
+        self._chk(lib().mort_hip_calib_hbm_copy(self._h, nbytes, reps, C.byref(g)), "mort_hip_calib_hbm_copy")
+        return g.value
 
 
 def seed_states_host(seed, width, height, dtype=None):

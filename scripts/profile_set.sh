@@ -17,7 +17,7 @@ if [[ $PARTS == *bench* ]]; then
   tail -1 $O/${TAG}_bench.json | cut -c1-400
 fi
 if [[ $PARTS == *stats* ]]; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 bench.py $BARGS --steps $STEPS --warmup 1 --cpu-spp 0 > $O/${TAG}_stats.log 2>&1 || { tail -5 $O/${TAG}_stats.log; exit 1; }
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -- python3 bench.py $BARGS --steps $STEPS --warmup 1 --cpu-spp 0 --no-calib --no-throughput-line > $O/${TAG}_stats.log 2>&1 || { tail -5 $O/${TAG}_stats.log; exit 1; }
   cp $(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv && head -4 $O/${TAG}_kernel_stats.csv
   rm -rf $O/${TAG}_stats
 fi

@@ -170,3 +170,40 @@ def test_scripted_input_frames(tmp_path, oracle):
     lf2 = np.array(list(cam.lookfrom.e)); u2 = np.array(list(cam.u.e))
     L.mort_camera_input(C.byref(cam), 8, 0, 0, 0)
     assert np.allclose(list(cam.lookfrom.e), lf2 + u2, atol=1e-5)
+
+
+@pytest.mark.parametrize("env", [{"MORT_TEST_FAIL_RANK": "1", "MORT_TEST_BLOCK_RANK0": "1"}, {"MORT_TEST_FAIL_RANK": "2", "MORT_TEST_BLOCK_RANK0": "1"}, {"MORT_TEST_FAIL_RANK": "0"}])
+def test_a_failed_rank_takes_the_others_down(env):
+    """`--gpus N`: the frame gather is collective, so a rank that fails must not leave rank 0 waiting in ncclRecv (or a peer in ncclSend)
+    for ever.  mort.c's hooks make one rank fail right after the fork while rank 0 / the healthy peers wait as they would inside the
+    gather: the whole job exits non-zero at once and leaves no process behind.  No GPU needed."""
+    import time
+    t0 = time.time()
+    p = subprocess.run([MORT, "1", "--width", "64", "--spp", "1", "--gpus", "3", "--gather", "shm"], cwd=ROOT, capture_output=True, text=True,
+                       timeout=50, env={**os.environ, **env})
+    assert p.returncode not in (0, 3), p.stdout + p.stderr
+    assert time.time() - t0 < 20, "the job waited for a rank that could never arrive"
+    assert "MORT_TEST_FAIL_RANK" in p.stderr
+    time.sleep(0.3)
+    left = subprocess.run(["ps", "-eo", "args"], capture_output=True, text=True).stdout
+    assert not [l for l in left.splitlines() if l.startswith(MORT + " 1 --width 64 --spp 1 --gpus 3")], "a rank outlived the failed job"
+
+
+@pytest.mark.gpu
+def test_gpu_scripted_input_frames(tmp_path, oracle):
+    """SURVEY f4 on the GPU: `mort 10 --frames 2 --keys W` -- input(), initialize(), render with the per-pixel streams continuing from
+    frame 1 (mort.cu:49-120) -- against the oracle driven the same way."""
+    import ctypes as C
+    L = host.lib()
+    world, cam = host.build_scene(10, width=96, spp=4)
+    L.mort_camera_input.argtypes = [C.POINTER(type(cam)), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.mort_camera_input.restype = None
+    r1 = oracle.render(world, cam, nthreads=8)
+    L.mort_camera_input(C.byref(cam), 1, 0, 0, 0)
+    r2 = oracle.render(world, cam, nthreads=8, states=r1["states"].copy())
+    ppm, sts = tmp_path / "f2.ppm", tmp_path / "f2.states"
+    p = run(10, "--width", 96, "--spp", 4, "--frames", 2, "--keys", "W", "--out", ppm, "--states-out", sts)
+    assert last_json(p)["kernel"].startswith("mega_bvh_kernel")
+    assert (read_ppm(ppm) == r2["rgba"][..., :3]).all() and not (r1["rgba"] == r2["rgba"]).all()
+    st = np.fromfile(sts, dtype=oracle.STATE_DTYPE)
+    assert (st["d"] == r2["states"]["d"].reshape(-1)).all() and (st["v"] == r2["states"]["v"].reshape(-1, 5)).all()
