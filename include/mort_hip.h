@@ -154,7 +154,10 @@ typedef struct mort_calib_valu {
     double cycles_per_wave;          /* s_memtime ticks around the loop, median over waves */
     double clock_ghz;                /* s_memtime ticks per s_memrealtime tick (100 MHz), median over waves */
     double valu_per_wave;            /* VALU instructions each wave issued */
-    double cycles_per_valu_per_simd; /* cycles_per_wave / (valu_per_wave * waves_per_simd) */
+    int simds_seen;                  /* distinct (XCC, SE, SH, CU, SIMD) the waves reported (HW_REG_HW_ID / HW_REG_XCC_ID) */
+    double resident_waves_per_simd;  /* waves of this launch that really overlapped on a SIMD (median over SIMDs) */
+    double cycles_per_valu_per_wave; /* what ONE wave sustains: cycles_per_wave / valu_per_wave */
+    double cycles_per_valu_per_simd; /* what a SIMD sustains: (first start .. last end of its waves) x clock / instructions issued on it, median over SIMDs */
 } mort_calib_valu;
 int mort_hip_calib_valu(mort_ctx *ctx, int waves_per_simd, int kind, mort_calib_valu *out);
 int mort_hip_calib_hbm_copy(mort_ctx *ctx, size_t bytes, int reps, double *gbs_out);

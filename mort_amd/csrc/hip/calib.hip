@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "mort_hip.h"
@@ -66,8 +68,12 @@ __global__ void __launch_bounds__(256) calib_valu_kernel(int iters, float x, flo
     if (s == 12345.678f && sacc == 7) out[0] = 1; /* keeps the chains alive */
     if ((threadIdx.x & 63) == 0) {
         const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-        out[8 + 2 * w] = t1 - t0;
-        out[9 + 2 * w] = r1 - r0;
+        /* where the wave ran: HW_REG_HW_ID (id 4: simd [5:4], cu [11:8], sh [12], se [15:13]) and HW_REG_XCC_ID (id 20, [3:0]) */
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        out[8 + 4 * w] = t1 - t0;
+        out[9 + 4 * w] = r0;
+        out[10 + 4 * w] = r1;
+        out[11 + 4 * w] = ((unsigned long long)(xcc & 0xfu) << 16) | (unsigned long long)(hw & 0xff30u);
     }
 }
 
@@ -77,14 +83,15 @@ extern "C" int mort_hip_calib_valu(mort_ctx *c, int waves_per_simd, int kind, mo
     void (*kern)(int, float, float, unsigned long long *) =
         kind == 0 ? calib_valu_kernel<0> : kind == 1 ? calib_valu_kernel<1> : kind == 2 ? calib_valu_kernel<2> : calib_valu_kernel<3>;
     const int blocks = c->num_cus * waves_per_simd;
-    /* exactly waves_per_simd blocks fit a CU's 160 KB */
-    const size_t lds = ((size_t)160 * 1024 / (size_t)waves_per_simd) & ~(size_t)255;
+    /* exactly waves_per_simd blocks fit a CU's 160 KB (the hardware hands LDS out in granules: a request that is not a multiple of
+     * 2 KB is rounded up, and one block fewer fits than the byte count says) */
+    const size_t lds = ((size_t)160 * 1024 / (size_t)waves_per_simd) & ~(size_t)2047;
     HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 0;
     HIPCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
     if (per_cu != waves_per_simd) { c->last_error = "calib_valu: occupancy query disagrees with the LDS sizing"; return MORT_ERR_HIP; }
     unsigned long long *d_out = nullptr;
-    const size_t n_out = 8 + 2 * (size_t)blocks * 4;
+    const size_t n_out = 8 + 4 * (size_t)blocks * 4;
     HIPCHK(c, hipMalloc((void **)&d_out, n_out * sizeof(unsigned long long)));
     const int iters = 20000 / waves_per_simd + 2000;
     int st = MORT_OK;
@@ -105,26 +112,54 @@ extern "C" int mort_hip_calib_valu(mort_ctx *c, int waves_per_simd, int kind, mo
     if (e1) hipEventDestroy(e1);
     hipFree(d_out);
     if (st != MORT_OK) return st;
+    /* per wave: loop cycles and its clock; per SIMD (xcc, se, sh, cu, simd of HW_ID): the waves that ran there, how many of them at
+     * once, and the SIMD's cycles per instruction = (its first start .. its last end) x clock / instructions issued there */
     std::vector<double> cyc, clk;
+    struct Simd { double first = 1e300, last = 0; int waves = 0; std::vector<std::pair<double, int>> ev; };
+    std::map<unsigned long long, Simd> simds;
     for (size_t w = 0; w < (size_t)blocks * 4; w++) {
-        const double t = (double)h[8 + 2 * w], r = (double)h[9 + 2 * w];
-        if (t > 0 && r > 0) { cyc.push_back(t); clk.push_back(t / r * 0.1); } /* s_memrealtime ticks at 100 MHz */
+        const double t = (double)h[8 + 4 * w], r0 = (double)h[9 + 4 * w], r1 = (double)h[10 + 4 * w];
+        if (!(t > 0 && r1 > r0)) continue;
+        cyc.push_back(t); clk.push_back(t / (r1 - r0) * 0.1); /* s_memrealtime ticks at 100 MHz */
+        Simd &sd = simds[h[11 + 4 * w]];
+        sd.first = std::min(sd.first, r0); sd.last = std::max(sd.last, r1); sd.waves++;
+        sd.ev.push_back({r0, +1}); sd.ev.push_back({r1, -1});
     }
     if (cyc.empty()) return MORT_ERR_HIP;
     std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
     const double valu_per_wave = (double)iters * CALIB_UNROLL * (kind == 3 ? 12.0 : (double)CALIB_CHAINS);
+    const double clock = clk[clk.size() / 2];
+    std::vector<double> cpi, conc;
+    for (auto &kv : simds) {
+        Simd &sd = kv.second;
+        cpi.push_back((sd.last - sd.first) * 10.0 * clock / (valu_per_wave * sd.waves)); /* ticks x 10 ns x GHz = cycles */
+        std::sort(sd.ev.begin(), sd.ev.end());
+        int cur = 0, mx = 0;
+        for (auto &e : sd.ev) { cur += e.second; mx = std::max(mx, cur); }
+        conc.push_back((double)mx);
+    }
+    std::sort(cpi.begin(), cpi.end()); std::sort(conc.begin(), conc.end());
     res->waves_per_simd = waves_per_simd; res->kind = kind;
     res->seconds = ms * 1e-3;
     res->cycles_per_wave = cyc[cyc.size() / 2];
-    res->clock_ghz = clk[clk.size() / 2];
+    res->clock_ghz = clock;
     res->valu_per_wave = valu_per_wave;
-    res->cycles_per_valu_per_simd = res->cycles_per_wave / (valu_per_wave * (double)waves_per_simd);
+    res->simds_seen = (int)simds.size();
+    res->resident_waves_per_simd = conc[conc.size() / 2];
+    res->cycles_per_valu_per_wave = res->cycles_per_wave / valu_per_wave;
+    res->cycles_per_valu_per_simd = cpi[cpi.size() / 2];
     return MORT_OK;
 }
 
 __global__ void __launch_bounds__(256) calib_copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16) {
+    /* four 16-byte loads in flight per lane before the stores */
     const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 extern "C" int mort_hip_calib_hbm_copy(mort_ctx *c, size_t bytes, int reps, double *gbs_out) {
@@ -137,7 +172,7 @@ extern "C" int mort_hip_calib_hbm_copy(mort_ctx *c, size_t bytes, int reps, doub
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (hipMemsetAsync(a, 1, bytes, c->stream) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) st = MORT_ERR_HIP;
     const size_t n16 = bytes / 16;
-    const int grid = c->num_cus * 8;
+    const int grid = c->num_cus * 16;
     double best = 0;
     for (int r = 0; r <= reps && st == MORT_OK; r++) { /* r = 0 warms up */
         hipEventRecord(e0, c->stream);

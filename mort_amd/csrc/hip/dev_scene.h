@@ -116,7 +116,9 @@ struct DScene {
      * world-order copies of every sphere / quad and of the hittable lists */
     const DSphere *wspheres; const DQuad *wquads;
     const int *list_types; const int *list_idxs; /* concatenated */
-    int list_first[MORT_NUM_HITTABLE_LIST]; int list_count[MORT_NUM_HITTABLE_LIST];
+    /* per hittable_list: [MORT_NUM_HITTABLE_LIST] each.  Pointers into the blob, not arrays: a kernel's local view of the scene
+     * must not hold a dynamically indexed member (it would live in private memory) */
+    const int *list_first; const int *list_count;
     uint32_t blob_bytes;    /* size of everything above texels/noise (LDS staging candidate) */
     uint32_t lds_bytes;     /* bytes the staged part needs */
 };

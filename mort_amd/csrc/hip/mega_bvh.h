@@ -67,6 +67,7 @@ struct FastArgs {
      * covers a VIRTUAL image of local_rows * sub rows: virtual row = row * sub + s_j; r.states / vaccum are indexed by virtual pixel */
     int sub;                    /* 0, or sqrt_spp in sub-stream launches */
     float *vaccum;              /* sub-stream launches: per virtual pixel, the unscaled colour sum of its stratum row (3 floats) */
+    float4 *deep;               /* bounce-stack levels >= stack_lds_depth: [level - stack_lds_depth][lane of the launch] (HBM, coalesced per wave) */
 };
 
 enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };

@@ -14,6 +14,7 @@ struct GenArgs {
     uint32_t o_nodes, o_leaves, o_entries, o_chains, o_xforms, o_items, o_subitems, o_media;
     uint32_t o_lambert, o_metal, o_diel, o_dlight, o_iso, o_solid, o_checker, o_image;
     uint32_t o_spheres, o_quads, o_wspheres, o_wquads, o_ltypes, o_lidxs; /* valid when prims_in_lds */
+    uint32_t o_lfirst, o_lcount; /* per hittable_list: first / count in the concatenated list tables (always in the image) */
     int prims_in_lds;
     const uint32_t *ranks; /* scan-order ranks (HBM, behind the LDS part of the image): equal-t ties only */
     int n_spheres;
@@ -23,7 +24,6 @@ struct GenArgs {
     float gx, gy, gz, gR, mnear, kmin; /* far-origin rays widen their error band (scene_compile.h) */
     int th_m;          /* lanes waiting in the media state that trigger a media step */
     int probe;         /* 1 = one-sample cost probe: no image / state output */
-    int lane_walk;     /* test knob (MORT_GEN_LANE_WALK=1): every lane runs the whole search by itself (dev_gen.h gen_world_hit) */
 };
 
 /* host side (mega_gen.hip) */

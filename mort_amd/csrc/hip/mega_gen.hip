@@ -34,7 +34,7 @@
 
 #include "mega_gen.h"
 #include "dev_gen.h"
-#include "dev_shade_call.h"
+#include "dev_shade.h"
 
 #pragma clang fp contract(off)
 
@@ -54,51 +54,122 @@ __device__ __attribute__((noinline)) ScanHit scan_solids(const DScene *scp, int 
     return h;
 }
 
+/* ---- launch arguments without private memory ----
+ * Round 2's kernel took `&ga` for its out-of-line helpers, so hipcc kept a PRIVATE copy of the 800-byte argument struct per lane
+ * and read wave-uniform fields from it inside the state loop: 38 KB of scratch per wave for the copy alone, far more than the L2
+ * share of a CU, so every such read was a trip to the Infinity Cache (1.0-1.5 TB of L2 <-> fabric traffic per frame of the final
+ * scene).  Now: the by-value parameter is never named; the kernarg segment is copied once into LDS (s_ga), every
+ * wave-uniform value the state loop needs is moved from there into an SGPR (readfirstlane: the compiler can neither re-load nor
+ * re-materialise it), and the rare out-of-line helpers get the kernarg segment's own address. */
+__device__ __forceinline__ int uni_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uni_u(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ float uni_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+template <typename T> __device__ __forceinline__ T *uni_p(T *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = uni_u((uint32_t)v), hi = uni_u((uint32_t)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
+
+/* primitive records that stay in HBM / L2 (worlds whose primitives do not fit in LDS): loaded as global dwordx4, not through a flat
+ * pointer (a flat load counts on the LDS counter too, and the leaf step waits on LDS all the time) */
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef const v4f_t __attribute__((address_space(1))) *gv4_ptr;
+template <bool IN_LDS> __device__ __forceinline__ DSphere load_sphere(const DSphere *base, uint32_t idx) {
+    if (IN_LDS) return base[idx];
+    const gv4_ptr p = (gv4_ptr)(unsigned long long)(base + idx);
+    const v4f_t a = p[0], b = p[1];
+    DSphere s;
+    s.cx = a.x; s.cy = a.y; s.cz = a.z; s.radius = a.w; s.vx = b.x; s.vy = b.y; s.vz = b.z; s.mat = __float_as_uint(b.w);
+    return s;
+}
+template <bool IN_LDS> __device__ __forceinline__ DQuad load_quad(const DQuad *base, uint32_t idx) {
+    if (IN_LDS) return base[idx];
+    const gv4_ptr p = (gv4_ptr)(unsigned long long)(base + idx);
+    const v4f_t a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+    DQuad q;
+    q.Q[0] = a.x; q.Q[1] = a.y; q.Q[2] = a.z; q.D = a.w;
+    q.u[0] = b.x; q.u[1] = b.y; q.u[2] = b.z; q.area = b.w;
+    q.v[0] = c.x; q.v[1] = c.y; q.v[2] = c.z; q.mat = __float_as_uint(c.w);
+    q.n[0] = d.x; q.n[1] = d.y; q.n[2] = d.z; q.pad0 = 0;
+    q.w[0] = e.x; q.w[1] = e.y; q.w[2] = e.z; q.pad1 = 0;
+    return q;
+}
+
+#ifndef MORT_GEN_WAVES_512
+#define MORT_GEN_WAVES_512 2
+#endif
 /* SUB = true: MORT_MODE_THROUGHPUT's launch over (pixel, stratum row) work items with their own streams (mega_bvh.h FastArgs.sub) -- labelled, never parity */
 template <int BLOCK, bool PRIMS_LDS, bool SUB = false>
-__global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)) mega_gen_kernel(const GenArgs ga) {
+__global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MORT_GEN_WAVES_512 : MORT_GEN_MIN_WAVES)) mega_gen_kernel(const GenArgs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    __shared__ DScene s_lsc; /* the scene view below, for the out-of-line shade call */
-    __shared__ CamView s_cam;
-    const FastArgs &fa = ga.f;
-    const RenderArgs &a = fa.r;
+    __shared__ GenArgs s_ga;  /* the launch arguments, read from LDS (never from a private copy) */
+    __shared__ CamView s_cam; /* dev_render.h: get_ray's camera fields */
+    const GenArgs *const gap = (const GenArgs *)__builtin_amdgcn_kernarg_segment_ptr(); /* for the out-of-line helpers */
     {
-        const uint4 *src = (const uint4 *)fa.hot_src;
+        const uint32_t *src = (const uint32_t *)gap;
+        uint32_t *dst = (uint32_t *)&s_ga;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(GenArgs) / 4); i += BLOCK) dst[i] = src[i];
+    }
+    {
+        const uint4 *src = (const uint4 *)gap->f.hot_src;
         uint4 *dst = (uint4 *)lds;
-        const uint32_t n16 = fa.hot_bytes >> 4;
+        const uint32_t n16 = gap->f.hot_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
     }
     __syncthreads();
-    const DNode2 *nodes2 = (const DNode2 *)(lds + ga.o_nodes);
-    const uint32_t *leaves = (const uint32_t *)(lds + ga.o_leaves);
-    const uint32_t *entries = (const uint32_t *)(lds + ga.o_entries);
-    const int *chains = (const int *)(lds + ga.o_chains);
-    unsigned short *tstack = (unsigned short *)(lds + fa.off_tstack) + threadIdx.x; /* [level * BLOCK] */
+    if (threadIdx.x == 0) cam_view_fill(s_cam, s_ga.f.r);
+    __syncthreads();
+    const GenArgs &L = s_ga;
+    /* ---- wave-uniform values of the state loop, pinned in SGPRs ---- */
+    const DNode2 *nodes2 = (const DNode2 *)(lds + uni_u(L.o_nodes));
+    const uint32_t *leaves = (const uint32_t *)(lds + uni_u(L.o_leaves));
+    const uint32_t *entries = (const uint32_t *)(lds + uni_u(L.o_entries));
+    const int *chains = (const int *)(lds + uni_u(L.o_chains));
+    unsigned short *tstack = (unsigned short *)(lds + uni_u(L.f.off_tstack)) + threadIdx.x; /* [level * BLOCK] */
     /* this kernel's view of the scene: tables in LDS, big / rare ones (texels, Perlin tables, image descriptors for the
      * out-of-line lookups; primitives of big worlds) in HBM */
-    DScene lsc = a.sc;
-    lsc.items = (const DItem *)(lds + ga.o_items); lsc.subitems = (const DItem *)(lds + ga.o_subitems);
-    lsc.xforms = (const DXform *)(lds + ga.o_xforms); lsc.neg_inv_density = (const double *)(lds + ga.o_media);
-    lsc.lambert = (const DLambert *)(lds + ga.o_lambert); lsc.metal = (const DMetal *)(lds + ga.o_metal);
-    lsc.dielectric = (const DDielectric *)(lds + ga.o_diel); lsc.dlight = (const DLambert *)(lds + ga.o_dlight);
-    lsc.isotropic = (const DLambert *)(lds + ga.o_iso); lsc.solid = (const DSolid *)(lds + ga.o_solid);
-    lsc.checker = (const DChecker *)(lds + ga.o_checker); lsc.image = (const DImage *)(lds + ga.o_image);
+    DScene lsc;
+    lsc.n_items = uni_i(L.f.r.sc.n_items); lsc.n_subitems = 0; lsc.nodes = nullptr; lsc.n_nodes = 0;
+    lsc.n_spheres = 0; lsc.n_quads = 0; lsc.n_xforms = 0; lsc.n_media = 0; lsc.blob_bytes = 0; lsc.lds_bytes = 0;
+    lsc.items = (const DItem *)(lds + uni_u(L.o_items)); lsc.subitems = (const DItem *)(lds + uni_u(L.o_subitems));
+    lsc.xforms = (const DXform *)(lds + uni_u(L.o_xforms)); lsc.neg_inv_density = (const double *)(lds + uni_u(L.o_media));
+    lsc.lambert = (const DLambert *)(lds + uni_u(L.o_lambert)); lsc.metal = (const DMetal *)(lds + uni_u(L.o_metal));
+    lsc.dielectric = (const DDielectric *)(lds + uni_u(L.o_diel)); lsc.dlight = (const DLambert *)(lds + uni_u(L.o_dlight));
+    lsc.isotropic = (const DLambert *)(lds + uni_u(L.o_iso)); lsc.solid = (const DSolid *)(lds + uni_u(L.o_solid));
+    lsc.checker = (const DChecker *)(lds + uni_u(L.o_checker)); lsc.image = (const DImage *)(lds + uni_u(L.o_image));
+    lsc.list_first = (const int *)(lds + uni_u(L.o_lfirst)); lsc.list_count = (const int *)(lds + uni_u(L.o_lcount));
+    lsc.image_hbm = uni_p(L.f.r.sc.image_hbm); lsc.texels = uni_p(L.f.r.sc.texels); lsc.noise = uni_p(L.f.r.sc.noise);
     if (PRIMS_LDS) {
-        lsc.spheres = (const DSphere *)(lds + ga.o_spheres); lsc.quads = (const DQuad *)(lds + ga.o_quads);
-        lsc.wspheres = (const DSphere *)(lds + ga.o_wspheres); lsc.wquads = (const DQuad *)(lds + ga.o_wquads);
-        lsc.list_types = (const int *)(lds + ga.o_ltypes); lsc.list_idxs = (const int *)(lds + ga.o_lidxs);
+        lsc.spheres = (const DSphere *)(lds + uni_u(L.o_spheres)); lsc.quads = (const DQuad *)(lds + uni_u(L.o_quads));
+        lsc.wspheres = (const DSphere *)(lds + uni_u(L.o_wspheres)); lsc.wquads = (const DQuad *)(lds + uni_u(L.o_wquads));
+        lsc.list_types = (const int *)(lds + uni_u(L.o_ltypes)); lsc.list_idxs = (const int *)(lds + uni_u(L.o_lidxs));
+    } else {
+        lsc.spheres = uni_p(L.f.r.sc.spheres); lsc.quads = uni_p(L.f.r.sc.quads);
+        lsc.wspheres = uni_p(L.f.r.sc.wspheres); lsc.wquads = uni_p(L.f.r.sc.wquads);
+        lsc.list_types = uni_p(L.f.r.sc.list_types); lsc.list_idxs = uni_p(L.f.r.sc.list_idxs);
     }
-    if (ga.lane_walk & 2) lsc = a.sc; /* test knob: every table from HBM */
-    if (threadIdx.x == 0) { s_lsc = lsc; cam_view_fill(s_cam, a); }
-    __syncthreads();
     const DSphere *spheres = lsc.spheres;
     const DQuad *quads = lsc.quads;
+    const uint32_t *ranks = uni_p(L.ranks);
+    const int n_spheres = uni_i(L.n_spheres);
 
-    const int th_s = fa.th_s, th_l = fa.th_l, t_keep = fa.t_keep, th_m = ga.th_m;
-    const int spp = a.sqrt_spp * a.sqrt_spp;
-    const unsigned total_q = (unsigned)fa.tiles_total * 64u;
-    const int n_items = a.sc.n_items, first_medium = ga.first_medium;
+    const int th_s = uni_i(L.f.th_s), th_l = uni_i(L.f.th_l), t_keep = uni_i(L.f.t_keep), th_m = uni_i(L.th_m);
+    const int sqrt_spp = uni_i(L.f.r.sqrt_spp), bounce_limit = uni_i(L.f.r.bounce_limit);
+    const int light_type = uni_i(L.f.r.light_type), light_idx = uni_i(L.f.r.light_idx);
+    const float bg_x = uni_f(L.f.r.background.x), bg_y = uni_f(L.f.r.background.y), bg_z = uni_f(L.f.r.background.z);
+    const int spp = sqrt_spp * sqrt_spp;
+    const unsigned total_q = (unsigned)uni_i(L.f.tiles_total) * 64u;
+    const int n_items = lsc.n_items, first_medium = uni_i(L.first_medium);
     const bool has_media = first_medium < n_items;
+    const uint32_t root = uni_u(L.root);
+    const float g_x = uni_f(L.gx), g_y = uni_f(L.gy), g_z = uni_f(L.gz), g_R = uni_f(L.gR), g_mnear = uni_f(L.mnear), g_kmin = uni_f(L.kmin);
+    const int probe = uni_i(L.probe);
+    const int DL = uni_i(L.f.stack_lds_depth);
+    float4 *stack_lds = (float4 *)(lds + uni_u(L.f.off_stack)) + threadIdx.x; /* [level * BLOCK] */
+    /* bounce-stack levels below the LDS part: [level - DL][lane of the launch] in HBM, one coalesced 1 KB row per wave and level
+     * (a private array would be scratch memory, sized for the worst case in every lane) */
+    float4 *stack_deep = uni_p(L.f.deep) + ((size_t)blockIdx.x * BLOCK + threadIdx.x);
+    const size_t deep_stride = (size_t)gridDim.x * BLOCK;
 
     /* per-lane state */
     int state = G_S, kind = K_NEWPIX;
@@ -115,14 +186,11 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
     uint32_t node = 0;          /* T: tree node; L: leaf */
     int sp = 0, flags = 0;      /* pending far children; GFL_REF */
     V3 final_value = mk(0, 0, 0);
-    StackEntry stack_deep[MORT_MAX_BOUNCE_LIMIT];
     unsigned long long ident_mask = 0ull;
-    float4 *stack_lds = (float4 *)(lds + fa.off_stack);
-    const int DL = fa.stack_lds_depth;
 
 #ifdef MORT_PROFILE_STATES
     unsigned long long gp_steps[4] = {0, 0, 0, 0}, gp_lanes[4] = {0, 0, 0, 0}, gp_cyc[5] = {0, 0, 0, 0, 0}, gp_lprims = 0, gp_liters = 0;
-    unsigned long long gp_sp[6] = {0, 0, 0, 0, 0, 0}, gps0 = 0, gps1; /* S parts: stack store, finish, new pixel, new ray, decode, shade call */
+    unsigned long long gp_sp[6] = {0, 0, 0, 0, 0, 0}, gps0 = 0, gps1; /* S parts: stack store, finish, new pixel, new ray, decode, shade */
     unsigned long long gpt0 = __builtin_readcyclecounter(), gpt1;
 #define GPROFS0() do { gps0 = __builtin_readcyclecounter(); } while (0)
 #define GPROFS(i) do { gps1 = __builtin_readcyclecounter(); gp_sp[i] += gps1 - gps0; gps0 = gps1; } while (0)
@@ -184,28 +252,22 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
             uint32_t pos = 0;
             int cnt = 0;
             if (state == G_L) { const uint32_t rec = leaves[node]; pos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
-#ifndef MORT_GEN_NO_PREFETCH
             /* the record of the NEXT primitive is requested before this one is tested: with the primitives in HBM / L2 (the final scene's
              * 2 401 quads do not fit in LDS) a leaf is otherwise a chain of dependent load -> test -> load */
             uint32_t e_next = 0;
             DSphere sp_next; DQuad qd_next;
             sp_next.cx = sp_next.cy = sp_next.cz = sp_next.radius = sp_next.vx = sp_next.vy = sp_next.vz = 0; sp_next.mat = 0;
-            qd_next = quads[0];
-            if (cnt > 0) { e_next = entries[pos]; if (GENT_QUAD(e_next)) qd_next = quads[GENT_IDX(e_next)]; else sp_next = spheres[GENT_IDX(e_next)]; }
-#endif
+            qd_next = load_quad<PRIMS_LDS>(quads, 0);
+            if (cnt > 0) { e_next = entries[pos]; if (GENT_QUAD(e_next)) qd_next = load_quad<PRIMS_LDS>(quads, GENT_IDX(e_next)); else sp_next = load_sphere<PRIMS_LDS>(spheres, GENT_IDX(e_next)); }
             while (__ballot(cnt > 0) != 0ull) {
 #ifdef MORT_PROFILE_STATES
                 gp_liters++; gp_lprims += (unsigned long long)__popcll(__ballot(cnt > 0));
 #endif
                 if (cnt > 0) {
-#ifndef MORT_GEN_NO_PREFETCH
                     const uint32_t e = e_next;
                     const DSphere sp_cur = sp_next; const DQuad qd_cur = qd_next;
-                    if (cnt > 1) { e_next = entries[pos + 1]; if (GENT_QUAD(e_next)) qd_next = quads[GENT_IDX(e_next)]; else sp_next = spheres[GENT_IDX(e_next)]; }
-                    gen_leaf_test_rec(lsc, chains, ga.ranks, ga.n_spheres, sp_cur, qd_cur, e, ray, ray_a, closest, best, flags);
-#else
-                    gen_leaf_test(lsc, chains, ga.ranks, ga.n_spheres, spheres, quads, entries[pos], ray, ray_a, closest, best, flags);
-#endif
+                    if (cnt > 1) { e_next = entries[pos + 1]; if (GENT_QUAD(e_next)) qd_next = load_quad<PRIMS_LDS>(quads, GENT_IDX(e_next)); else sp_next = load_sphere<PRIMS_LDS>(spheres, GENT_IDX(e_next)); }
+                    gen_leaf_test_rec(lsc, chains, ranks, n_spheres, sp_cur, qd_cur, e, ray, ray_a, closest, best, flags);
                     pos++; cnt--;
                 }
             }
@@ -224,8 +286,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
              *      (constant_medium::hit, objects.cuh:396-434; world.cuh:154-160) ---- */
             if (state == G_M) {
                 if (flags) {
-                    atomicAdd(&a.counters[3], 1ull);
-                    const ScanHit h = scan_solids(&a.sc, first_medium, (const int *)(fa.hot_src + ga.o_chains), ga.n_chains, ray.o.x, ray.o.y, ray.o.z,
+                    atomicAdd(&gap->f.r.counters[3], 1ull);
+                    const ScanHit h = scan_solids(&gap->f.r.sc, first_medium, (const int *)(gap->f.hot_src + gap->o_chains), gap->n_chains, ray.o.x, ray.o.y, ray.o.z,
                                                   ray.d.x, ray.d.y, ray.d.z, ray.tm);
                     best = h.best; closest = h.closest;
                     flags = 0;
@@ -241,45 +303,40 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
             if (state == G_S) {
                 if (kind == K_SHADE) {
                     if (flags) { /* worlds without media come here directly */
-                        atomicAdd(&a.counters[3], 1ull);
-                        const ScanHit h = scan_solids(&a.sc, first_medium, (const int *)(fa.hot_src + ga.o_chains), ga.n_chains, ray.o.x, ray.o.y, ray.o.z,
+                        atomicAdd(&gap->f.r.counters[3], 1ull);
+                        const ScanHit h = scan_solids(&gap->f.r.sc, first_medium, (const int *)(gap->f.hot_src + gap->o_chains), gap->n_chains, ray.o.x, ray.o.y, ray.o.z,
                                                       ray.d.x, ray.d.y, ray.d.z, ray.tm);
                         best = h.best; closest = h.closest;
                         flags = 0;
                     }
 #ifdef MORT_DEBUG_PRINT
-                    if (lofs == a.debug_lofs) printf("[gen %d seg %u] o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) tm %.9g -> best %08x t %.9g draws %u\n", lofs, segments,
+                    if (lofs == L.f.r.debug_lofs) printf("[gen %d seg %u] o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) tm %.9g -> best %08x t %.9g draws %u\n", lofs, segments,
                         ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tm, best, closest, rng.draws);
 #endif
                     if (best == GBEST_NONE) { /* camera.cuh:154-158 */
-                        final_value = a.background;
+                        final_value = mk(bg_x, bg_y, bg_z);
                         kind = K_FINISH;
                     } else {
                         const Best b = gen_decode_best(lsc, chains, best, closest);
                         GPROFS(4);
+                        /* shade_hit in line: its tables are LDS addresses the compiler can see (ds_read, not flat loads), and nothing is
+                         * passed through memory.  (hipcc 7.2's SLP vectorizer miscompiled this form; the library is built without it,
+                         * Makefile.)  The parity tests against the oracle are what guards this. */
+                        const ShadeOut so = shade_hit(lsc, light_type, light_idx, ray, ray_time0, b, rng);
 #ifdef MORT_DEBUG_PRINT
-                        if (lofs == a.debug_lofs) printf("   decode: kind %d prim %d chain %d+%d t %.9g | chains[0..3] %d %d %d %d o_chains %u\n", b.kind, b.prim, b.chain_first, b.chain_count, b.t,
-                            chains[0], chains[1], chains[2], chains[3], ga.o_chains);
-#endif
-                        /* out of line (dev_shade_call.h): inlined here, hipcc 7.2 -O3 gives wrong scattered-ray origins for a few rays per
-                         * thousand (identical wrong bits with asm barriers around it, with guarded chain loops, with the scene read from
-                         * HBM or LDS; correct at -O1 and with a printf next to it) -- kept out of line, guarded by the parity tests */
-#ifdef MORT_SHADE_INLINE
-                        const ShadeOut so = shade_hit(s_lsc, a.light_type, a.light_idx, ray, ray_time0, b, rng);
-#else
-                        const ShadeOut so = shade_hit_outlined(&s_lsc, a.light_type, a.light_idx, ray, ray_time0, b, rng);
-#endif
-#ifdef MORT_DEBUG_PRINT
-                        if (lofs == a.debug_lofs) printf("   shaded: done %d ident %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", (int)so.done, (int)so.ident, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                        if (lofs == L.f.r.debug_lofs) printf("   shaded: done %d ident %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", (int)so.done, (int)so.ident, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
 #endif
                         GPROFS(5);
                         if (so.done) { final_value = so.final_value; kind = K_FINISH; }
                         else {
                             if (so.ident) ident_mask |= (1ull << iter);
-                            else if (iter < DL) { float4 e4; e4.x = so.e.kx; e4.y = so.e.ky; e4.z = so.e.kz; e4.w = so.e.rp; stack_lds[iter * BLOCK + threadIdx.x] = e4; }
-                            else stack_deep[iter] = so.e;
+                            else {
+                                float4 e4; e4.x = so.e.kx; e4.y = so.e.ky; e4.z = so.e.kz; e4.w = so.e.rp;
+                                if (iter < DL) stack_lds[iter * BLOCK] = e4;
+                                else stack_deep[(size_t)(iter - DL) * deep_stride] = e4;
+                            }
                             iter++;
-                            if (iter >= a.bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
+                            if (iter >= bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
                         }
                     }
                 }
@@ -289,25 +346,25 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         unsigned long long todo = ~ident_mask & (iter >= 64 ? ~0ull : ((1ull << iter) - 1ull));
                         if ((ident_mask >> (iter - 1)) & 1ull) final_value = vadd(mk(0, 0, 0), final_value);
                         /* four levels are fetched before they are applied (deepest first, as the reference unwinds): the deep levels live in
-                         * private memory, and one dependent load per level made a long path's unwind a chain of L2 round trips */
+                         * HBM, and one dependent load per level made a long path's unwind a chain of L2 round trips */
                         while (todo != 0ull) {
-                            StackEntry e[4];
+                            float4 e[4];
                             int n = 0;
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
                                 if (todo != 0ull) {
                                     const int lvl = 63 - __builtin_clzll(todo);
                                     todo &= ~(1ull << lvl);
-                                    if (lvl < DL) { const float4 e4 = stack_lds[lvl * BLOCK + threadIdx.x]; e[k].kx = e4.x; e[k].ky = e4.y; e[k].kz = e4.z; e[k].rp = e4.w; }
-                                    else e[k] = stack_deep[lvl];
+                                    if (lvl < DL) e[k] = stack_lds[lvl * BLOCK];
+                                    else e[k] = stack_deep[(size_t)(lvl - DL) * deep_stride];
                                     n = k + 1;
                                 }
                             }
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
                                 if (k < n) {
-                                    const V3 t = vmul(mk(e[k].kx, e[k].ky, e[k].kz), final_value);
-                                    final_value = vadd(mk(0, 0, 0), vscale(e[k].rp, t));
+                                    const V3 t = vmul(mk(e[k].x, e[k].y, e[k].z), final_value);
+                                    final_value = vadd(mk(0, 0, 0), vscale(e[k].w, t));
                                 }
                             }
                         }
@@ -318,23 +375,23 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                     s_ij++;
                     bool more; /* samples left in this work item (SUB: one stratum row) */
                     if constexpr (SUB) {
-                        more = (s_ij & 0xffff) != a.sqrt_spp;
+                        more = (s_ij & 0xffff) != sqrt_spp;
                     } else {
-                        if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
-                        more = (s_ij >> 16) < a.sqrt_spp;
+                        if ((s_ij & 0xffff) == sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
+                        more = (s_ij >> 16) < sqrt_spp;
                     }
                     if (more) {
                         kind = K_NEWSAMPLE;
                     } else {
-                        if constexpr (SUB) pixel_write<false, true>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
-                        else if (ga.probe) pixel_write<true>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
-                        else pixel_write<false>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        if constexpr (SUB) pixel_write<false, true>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        else if (probe) pixel_write<true>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        else pixel_write<false>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
                         kind = K_NEWPIX;
                     }
                 }
                 GPROFS(1);
                 if (kind == K_NEWPIX) {
-                    const PixelFetch pf = pixel_fetch<SUB>(&fa, total_q);
+                    const PixelFetch pf = pixel_fetch<SUB>(&gap->f, total_q);
                     if (!pf.got) state = G_DONE;
                     else {
                         xy = pf.xy; lofs = pf.lofs;
@@ -353,37 +410,16 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
                         ray_time0 = ray.tm;
                         iter = 0;
                         kind = K_SHADE;
-                        if (a.bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
+                        if (bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
                     }
                     if (kind == K_SHADE) { /* start world::hit for the new ray */
                         ray_a = vlen2(ray.d);
-                        const bool ordinary = gen_ray_setup(ray, ga.gx, ga.gy, ga.gz, ga.gR, ga.mnear, ga.kmin, gr);
+                        const bool ordinary = gen_ray_setup(ray, g_x, g_y, g_z, g_R, g_mnear, g_kmin, gr);
                         closest = __builtin_inff();
                         best = GBEST_NONE;
                         sp = 0;
                         flags = ordinary ? 0 : GFL_REF;
                         segments++;
-                        const uint32_t root = ga.root;
-                        if (ga.lane_walk & 1) { /* test knob: the whole search as one lane runs it (dev_gen.h), no scheduling */
-                            GenWalk gw;
-                            gw.nodes = nodes2; gw.leaves = leaves; gw.entries = entries; gw.chains = chains; gw.n_chains = ga.n_chains; gw.ranks = ga.ranks; gw.n_spheres = ga.n_spheres;
-                            gw.root = root; gw.first_medium = first_medium;
-                            gw.gx = ga.gx; gw.gy = ga.gy; gw.gz = ga.gz; gw.gR = ga.gR; gw.mnear = ga.mnear; gw.kmin = ga.kmin;
-                            Best b;
-                            const bool hit = gen_world_hit(lsc, gw, ray, rng, b, nullptr);
-                            closest = b.t;
-                            best = GBEST_NONE;
-                            if (hit) {
-                                if (b.kind == HIT_MEDIUM) best = GENT(0, GCHAIN_MEDIUM, (uint32_t)b.prim);
-                                else {
-                                    uint32_t cid = 0;
-                                    for (int k = 1; k < ga.n_chains; k++) if (chains[2 * k] == b.chain_first && chains[2 * k + 1] == b.chain_count) cid = (uint32_t)k;
-                                    best = GENT(b.kind == HIT_QUAD ? 1u : 0u, b.chain_count > 0 ? cid : 0u, (uint32_t)b.prim);
-                                }
-                            }
-                            flags = 0;
-                            state = G_S;
-                        } else
                         if (!ordinary) state = has_media ? G_M : G_S; /* the scan decides */
                         else if (root == 0xffffu) state = has_media ? G_M : G_S;
                         else { node = root & 0x7fffu; state = (root & 0x8000u) ? G_L : G_T; }
@@ -396,10 +432,11 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 512 ? 2 : MORT_GEN_MIN_WAVES)
     }
 #ifdef MORT_PROFILE_STATES
     if ((threadIdx.x & 63) == 0) {
-        for (int k = 0; k < 4; k++) { atomicAdd(&a.counters[4 + 2 * k], gp_steps[k]); atomicAdd(&a.counters[5 + 2 * k], gp_lanes[k]); }
-        for (int k = 0; k < 5; k++) atomicAdd(&a.counters[12 + k], gp_cyc[k]);
-        atomicAdd(&a.counters[17], gp_liters); atomicAdd(&a.counters[18], gp_lprims);
-        for (int k = 0; k < 6; k++) atomicAdd(&a.counters[20 + k], gp_sp[k]);
+        unsigned long long *counters = gap->f.r.counters;
+        for (int k = 0; k < 4; k++) { atomicAdd(&counters[4 + 2 * k], gp_steps[k]); atomicAdd(&counters[5 + 2 * k], gp_lanes[k]); }
+        for (int k = 0; k < 5; k++) atomicAdd(&counters[12 + k], gp_cyc[k]);
+        atomicAdd(&counters[17], gp_liters); atomicAdd(&counters[18], gp_lprims);
+        for (int k = 0; k < 6; k++) atomicAdd(&counters[20 + k], gp_sp[k]);
     }
 #endif
 }
@@ -413,6 +450,7 @@ static gen_kernel_t pick_kernel(int block, bool prims_in_lds, bool sub = false) 
         return nullptr;
     }
     switch (block) {
+    case 1024: return prims_in_lds ? mega_gen_kernel<1024, true> : mega_gen_kernel<1024, false>;
     case 768: return prims_in_lds ? mega_gen_kernel<768, true> : mega_gen_kernel<768, false>;
     case 512: return prims_in_lds ? mega_gen_kernel<512, true> : mega_gen_kernel<512, false>;
     case 256: return prims_in_lds ? mega_gen_kernel<256, true> : mega_gen_kernel<256, false>;

@@ -216,7 +216,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_substates); hipFree(c->d_vaccum);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
-    hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states);
+    hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states); hipFree(c->d_deep);
     if (c->h_live) hipHostFree(c->h_live);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -292,6 +292,8 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
         g.o_lambert = (uint32_t)place(gb, o.lambert); g.o_metal = (uint32_t)place(gb, o.metal); g.o_diel = (uint32_t)place(gb, o.dielectric);
         g.o_dlight = (uint32_t)place(gb, o.dlight); g.o_iso = (uint32_t)place(gb, o.isotropic);
         g.o_solid = (uint32_t)place(gb, o.solid); g.o_checker = (uint32_t)place(gb, o.checker); g.o_image = (uint32_t)place(gb, o.image);
+        g.o_lfirst = (uint32_t)place(gb, std::vector<int>(o.list_first, o.list_first + MORT_NUM_HITTABLE_LIST));
+        g.o_lcount = (uint32_t)place(gb, std::vector<int>(o.list_count, o.list_count + MORT_NUM_HITTABLE_LIST));
         const size_t prim_bytes = o.spheres.size() * sizeof(DSphere) + o.quads.size() * sizeof(DQuad) + o.wspheres.size() * sizeof(DSphere) +
                                   o.wquads.size() * sizeof(DQuad) + (o.list_types.size() + o.list_idxs.size()) * sizeof(int) + 6 * 32;
         if (gb.size() + prim_bytes <= 48 * 1024) {
@@ -578,6 +580,7 @@ static int ensure_substates(mort_ctx *c, int W, int H, int S, hipStream_t s) {
 /* d_segpx: per-pixel segment counts for the packed owned rows, or null.  Only mort_hip_render passes one (sized for
  * THIS image and partition); the public device entry never does, so a buffer left over from an earlier, smaller
  * render can not be written past its end. */
+static int ensure_buf(mort_ctx *c, void **p, size_t *cap, size_t need);
 static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum, uint32_t *d_segpx,
                               void *stream, mort_stats *stats) {
     if (!c || !cam || !d_rgba) return MORT_ERR_INVALID;
@@ -792,16 +795,15 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
           else { /* 512 threads = 2 waves per SIMD: the state loop fits its 256-VGPR budget without spilling (at 3 waves it spills 44
                   * registers and the final scene is 9 % slower); fewer pixels than lanes: 256-thread groups so every CU has work */
                  FB = (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
-        if (FB != 768 && FB != 512 && FB != 256) FB = 256;
+        if (FB != 1024 && FB != 768 && FB != 512 && FB != 256) FB = 256;
         /* swept on the final scene, 800x800x100 (scripts/th_sweep.py, 180 settings): 373 ms here vs 449 ms with the BVH kernel's (40,24,12) and m = 24 */
         fa.th_s = 28; fa.th_l = 20; fa.t_keep = 4; ga.th_m = 56;
-        { const char *lw = std::getenv("MORT_GEN_LANE_WALK"); ga.lane_walk = lw ? std::atoi(lw) : 0; }
         { const char *th = std::getenv("MORT_GEN_THRESHOLDS"); /* "s,l,k,m" */
           if (th) { int s_ = 0, l_ = 0, k_ = 0, m_ = 0; if (std::sscanf(th, "%d,%d,%d,%d", &s_, &l_, &k_, &m_) == 4) { fa.th_s = s_; fa.th_l = l_; fa.t_keep = k_; ga.th_m = m_; } } }
         const uint32_t tstack_off = (c->gen_bytes + 15u) & ~15u;
         const uint32_t stack_off = tstack_off + (uint32_t)MORT_OWN_STACK * (uint32_t)FB * 2u;
         fa.off_tstack = tstack_off;
-        const int groups_per_cu = FB == 512 ? 1 : 768 / FB;
+        const int groups_per_cu = (FB == 512 || FB == 1024) ? 1 : 768 / FB;
         uint32_t static_lds = 512; /* the kernel's own __shared__ objects come out of the same 160 KB */
         { hipFuncAttributes fattr; if (mort_gen_attributes(FB, ga.prims_in_lds != 0, &fattr, substream) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 255) & ~(size_t)255); }
         int dl = (int)(((160u * 1024u - static_lds) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
@@ -818,6 +820,12 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         if (grid < 1) grid = 1;
         lds_bytes_used = (int)lds_bytes;
         gen_block_used = FB;
+        { /* bounce-stack levels that do not fit in LDS: [level - dl][lane of the launch] in HBM */
+            const int deep_levels = cam->bounce_limit > dl ? cam->bounce_limit - dl : 0;
+            int st_d = ensure_buf(c, &c->d_deep, &c->deep_cap, (size_t)(deep_levels > 0 ? deep_levels : 1) * (size_t)grid * (size_t)FB * sizeof(float4));
+            if (st_d != MORT_OK) return st_d;
+            fa.deep = (float4 *)c->d_deep;
+        }
         std::snprintf(kname, sizeof kname, substream ? "mega_gen_kernel<%d, %s, true>" : "mega_gen_kernel<%d, %s>", FB, ga.prims_in_lds ? "true" : "false");
         if (!substream && !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
             int st_o = prepare_tile_order(c, cam, a, fa, tiles, grid, FB, false, s, [&](const FastArgs &pa) {

@@ -65,7 +65,7 @@ struct SceneBlob {
     mortc::Compiled comp;
     std::vector<unsigned char> bytes;
     size_t o_items, o_sub, o_nodes, o_sph, o_quads, o_xf, o_media, o_lamb, o_metal, o_diel, o_dl, o_iso, o_solid, o_chk, o_img;
-    size_t hot_bytes, o_wsph, o_wquads, o_lt, o_li, o_noise, o_tex;
+    size_t hot_bytes, o_wsph, o_wquads, o_lt, o_li, o_lf, o_lc, o_noise, o_tex;
 };
 
 /* MORT_OK, or the status upload_world returns for this world */
@@ -90,6 +90,8 @@ static inline int build_scene_blob(const mort_world *w, SceneBlob &sb) {
     sb.hot_bytes = (blob.size() + 15) & ~(size_t)15;
     sb.o_wsph = place(blob, o.wspheres); sb.o_wquads = place(blob, o.wquads);
     sb.o_lt = place(blob, o.list_types); sb.o_li = place(blob, o.list_idxs);
+    sb.o_lf = place(blob, std::vector<int>(o.list_first, o.list_first + MORT_NUM_HITTABLE_LIST));
+    sb.o_lc = place(blob, std::vector<int>(o.list_count, o.list_count + MORT_NUM_HITTABLE_LIST));
     sb.o_noise = place(blob, o.noise); sb.o_tex = place(blob, o.texels);
     return MORT_OK;
 }
@@ -113,7 +115,7 @@ static inline void scene_view(const SceneBlob &sb, const unsigned char *base, DS
     s.texels = base + sb.o_tex; s.noise = (const float *)(base + sb.o_noise);
     s.wspheres = (const DSphere *)(base + sb.o_wsph); s.wquads = (const DQuad *)(base + sb.o_wquads);
     s.list_types = (const int *)(base + sb.o_lt); s.list_idxs = (const int *)(base + sb.o_li);
-    for (int i = 0; i < MORT_NUM_HITTABLE_LIST; i++) { s.list_first[i] = o.list_first[i]; s.list_count[i] = o.list_count[i]; }
+    s.list_first = (const int *)(base + sb.o_lf); s.list_count = (const int *)(base + sb.o_lc);
     s.blob_bytes = (uint32_t)sb.hot_bytes;
     s.lds_bytes = (uint32_t)sb.hot_bytes;
 }

@@ -49,7 +49,8 @@ class Stats(C.Structure):
 
 class CalibValu(C.Structure):
     _fields_ = [("waves_per_simd", C.c_int), ("kind", C.c_int), ("seconds", C.c_double), ("cycles_per_wave", C.c_double),
-                ("clock_ghz", C.c_double), ("valu_per_wave", C.c_double), ("cycles_per_valu_per_simd", C.c_double)]
+                ("clock_ghz", C.c_double), ("valu_per_wave", C.c_double), ("simds_seen", C.c_int), ("resident_waves_per_simd", C.c_double),
+                ("cycles_per_valu_per_wave", C.c_double), ("cycles_per_valu_per_simd", C.c_double)]
 
 
 class MortHipError(RuntimeError):

@@ -14,7 +14,8 @@ with hip.Context(0) as ctx:
             r = ctx.calib_valu(w, kind)
             r["mix"] = KINDS[kind]
             out["valu"].append(r)
-            print(f"{KINDS[kind]:28s} waves/SIMD {w}: {r['cycles_per_valu_per_simd']:.3f} cycles per VALU per SIMD, clock {r['clock_ghz']:.2f} GHz, {r['seconds']*1e3:.2f} ms", file=sys.stderr, flush=True)
+            print(f"{KINDS[kind]:28s} asked {w} waves/SIMD, resident {r['resident_waves_per_simd']:.0f} on {r['simds_seen']} SIMDs: {r['cycles_per_valu_per_simd']:.3f} cycles per VALU per SIMD, "
+                  f"{r['cycles_per_valu_per_wave']:.3f} per wave, clock {r['clock_ghz']:.2f} GHz, {r['seconds']*1e3:.2f} ms", file=sys.stderr, flush=True)
     out["hbm_copy_GBs"] = ctx.calib_hbm_copy(1 << 30, 5)
     print(f"float4 copy, 1 GiB per buffer: {out['hbm_copy_GBs']:.0f} GB/s (read + write)", file=sys.stderr)
 s = json.dumps(out, indent=1)
