@@ -13,6 +13,8 @@ HIPCC ?= $(ROCM)/bin/hipcc
 CC ?= gcc
 ARCH ?= gfx950
 
+# diagnostic builds (cycle counters, region marks) may spill: make hip RESCHECK= ...
+RESCHECK ?= --check
 LIBDIR := mort_amd/lib
 BINDIR := mort_amd/bin
 INC := -Iinclude
@@ -28,7 +30,7 @@ HOST_SRC := mort_amd/csrc/host/mort_host.c mort_amd/csrc/host/mort_scenes.c mort
 HIP_SRC := $(wildcard mort_amd/csrc/hip/*.hip)
 HIP_HDR := $(wildcard mort_amd/csrc/hip/*.h) $(wildcard include/*.h)
 
-.PHONY: all host hip oracle cli clean
+.PHONY: all host hip oracle cli clean resources
 all: host oracle hip cli
 
 host: $(LIBDIR)/libmort_host.so
@@ -47,6 +49,11 @@ $(OBJDIR)/%.o: mort_amd/csrc/hip/%.hip $(HIP_HDR)
 $(LIBDIR)/libmort_hip.so: $(HIP_OBJ)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=$(ARCH) -fno-gpu-rdc -shared -o $@ $(HIP_OBJ) -lpthread -ldl
+	@python3 scripts/kernel_resources.py $@ $(RESCHECK) > $(OBJDIR)/kernel_resources.txt || { cat $(OBJDIR)/kernel_resources.txt; rm -f $@; exit 1; }
+
+# per-kernel registers / spills / private memory / LDS as the code objects state them (also checked by `make hip`)
+resources: $(LIBDIR)/libmort_hip.so
+	python3 scripts/kernel_resources.py $(LIBDIR)/libmort_hip.so
 
 oracle:
 	$(MAKE) -C oracle all ref

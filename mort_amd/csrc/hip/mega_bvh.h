@@ -68,7 +68,38 @@ struct FastArgs {
     int sub;                    /* 0, or sqrt_spp in sub-stream launches */
     float *vaccum;              /* sub-stream launches: per virtual pixel, the unscaled colour sum of its stratum row (3 floats) */
     float4 *deep;               /* bounce-stack levels >= stack_lds_depth: [level - stack_lds_depth][lane of the launch] (HBM, coalesced per wave) */
+    /* priority pixels (mega_gen.hip): the pixels of the first prio_tiles tiles of the cost order are handed out prio_lanes per fetch from
+     * their own cursor (next_q[1]), so that every wave holds at most a few of the frame's longest chains, and flagged: their wave runs
+     * the state THEY are in next (PixelFetch.prio).  0 = none */
+    int prio_tiles, prio_lanes;
+    unsigned long long *wave_log; /* profile builds (-DMORT_PROFILE_STATES) with MORT_WAVE_LINES=1: 16 words per wave of the launch, else null */
 };
+
+#ifdef MORT_BVH_PRIVATE_ARGS
+#define MORT_BVH_ARG_NAME fa_byval
+#else
+#define MORT_BVH_ARG_NAME
+#endif
+#ifdef MORT_BVH_NO_PIN /* measured variant: uniform values are read where they are used, not pinned in SGPRs */
+#define BU_I(x) (x)
+#define BU_U(x) (x)
+#define BU_F(x) (x)
+#define BU_P(x) (x)
+#else
+#define BU_I(x) uni_i(x)
+#define BU_U(x) uni_u(x)
+#define BU_F(x) uni_f(x)
+#define BU_P(x) uni_p(x)
+#endif
+/* a wave-uniform value moved into an SGPR: the compiler can neither re-load nor re-materialise it inside the state loop */
+__device__ __forceinline__ int uni_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uni_u(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ float uni_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+template <typename T> __device__ __forceinline__ T *uni_p(T *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const uint32_t lo = uni_u((uint32_t)v), hi = uni_u((uint32_t)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
+}
 
 enum { ST_T = 0, ST_L = 1, ST_S = 2, ST_DONE = 3 };
 enum { FL_TIE = 1, FL_REF = 2 };
@@ -248,7 +279,7 @@ __device__ __attribute__((noinline)) void pixel_write(const FastArgs *fap, float
         atomicAdd(&a.counters[slot + 1u], (unsigned long long)draws);
     }
 }
-struct PixelFetch { int got; /* 0, or 1 + the stratum row (SUB) */ int xy, lofs; uint32_t d, v0, v1, v2, v3, v4; };
+struct PixelFetch { int got; /* 0, or 1 + the stratum row (SUB) */ int xy /* x | y << 16 | priority pixel << 31 */, lofs; uint32_t d, v0, v1, v2, v3, v4; };
 /* one atomicAdd per wave per refill; the lanes that call this together take consecutive slots */
 template <bool SUB = false>
 __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap, unsigned total_q) {
@@ -258,13 +289,28 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
     const int vrows = SUB ? a.local_rows * fa.sub : a.local_rows; /* rows of the (virtual) image the tiles cover */
     bool done = false;
     while (!done) {
-        const unsigned long long need = __ballot(1);
-        const int cnt = __popcll(need);
-        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
-        unsigned base = 0;
-        if (rank == 0) base = atomicAdd(fa.next_q, (unsigned)cnt);
-        base = __shfl(base, __ffsll((long long)need) - 1);
-        const unsigned q = base + (unsigned)rank;
+        unsigned long long need = __ballot(1);
+        int cnt = __popcll(need);
+        int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+        unsigned q = 0;
+        bool from_a = false;
+        const unsigned total_a = SUB ? 0u : (unsigned)fa.prio_tiles * 64u;
+        if (total_a) { /* the head of the cost order: at most prio_lanes pixels of it per fetch */
+            const int ka = cnt < fa.prio_lanes ? cnt : fa.prio_lanes;
+            unsigned base_a = 0;
+            if (rank == 0) base_a = atomicAdd(fa.next_q + 1, (unsigned)ka);
+            base_a = __shfl(base_a, __ffsll((long long)need) - 1);
+            if (rank < ka && base_a + (unsigned)rank < total_a) { q = base_a + (unsigned)rank; from_a = true; }
+        }
+        if (!from_a) {
+            need = __ballot(1);
+            cnt = __popcll(need);
+            rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
+            unsigned base = 0;
+            if (rank == 0) base = atomicAdd(fa.next_q, (unsigned)cnt);
+            base = __shfl(base, __ffsll((long long)need) - 1);
+            q = total_a + base + (unsigned)rank;
+        }
         if (q >= total_q) break; /* pool empty */
         /* slot -> (tile rank, pixel of the tile).  A lane's chain advances one segment per round of its
          * wave's state loop, and a round is slowest when all 64 lanes carry long chains; neighbouring
@@ -274,7 +320,7 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
          * group u -> tile rank g*G + (w + u*S) mod G, pixel group u of that tile: a rotation per u,
          * hence a bijection between slots and pixels. */
         int tslot = (int)(q >> 6), within = (int)(q & 63u);
-        if (fa.gen_tiles > 0) {
+        if (fa.gen_tiles > 0 && !from_a) {
             const int g = tslot / fa.gen_tiles, w = tslot - g * fa.gen_tiles;
             const int left = fa.tiles_total - g * fa.gen_tiles;
             const int G = left < fa.gen_tiles ? left : fa.gen_tiles;
@@ -287,7 +333,7 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
         const int qx = tx * 8 + (within & 7), qly = ty * 8 + (within >> 3);
         if (qx < a.width && qly < vrows) {
             const int rly = SUB ? qly / fa.sub : qly; /* the pixel's local row; SUB: qly = row * sub + stratum row */
-            pf.xy = qx | (global_row(rly, a.rank, a.nranks, a.rows_per_block) << 16);
+            pf.xy = qx | (global_row(rly, a.rank, a.nranks, a.rows_per_block) << 16) | (from_a ? (int)0x80000000u : 0);
             pf.lofs = qx + qly * a.width;
             pf.got = SUB ? 1 + (qly - rly * fa.sub) : 1;
             done = true;
@@ -309,34 +355,52 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
  * (A thin wrapper kernel around a shared body would keep the three-parameter symbol names, but it perturbs the frame kernel's register
  * allocation: 136 instead of 122 scratch instructions) */
 template <int BLOCK, bool PROBE, bool DRAIN = false, bool SUB = false>
-__global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) / 256 : MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs fa) {
+__global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) / 256 : MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs MORT_BVH_ARG_NAME) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    /* The by-value parameter is never named: round 2's kernel took its address for the out-of-line helpers, so hipcc kept a private
+     * copy of the argument struct per lane (592 B of scratch) and read wave-uniform fields from it inside the state loop.  The kernarg
+     * segment is copied into LDS once, the loop's uniform values are pinned in SGPRs, the helpers get the segment's own address. */
     __shared__ CamView s_cam; /* dev_render.h: get_ray's camera fields, read from LDS */
-    const RenderArgs &a = fa.r;
+#ifdef MORT_BVH_PRIVATE_ARGS /* round 2's form, kept as a measured variant: helpers get &fa, hipcc keeps a private copy */
+    const FastArgs *const fap = &fa_byval;
+    const FastArgs &s_fa = fa_byval;
+#else
+    __shared__ FastArgs s_fa;
+    const FastArgs *const fap = (const FastArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     {
-        const uint4 *src = (const uint4 *)fa.hot_src;
+        const uint32_t *src = (const uint32_t *)fap;
+        uint32_t *dst = (uint32_t *)&s_fa;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(FastArgs) / 4); i += BLOCK) dst[i] = src[i];
+    }
+#endif
+    {
+        const uint4 *src = (const uint4 *)fap->hot_src;
         uint4 *dst = (uint4 *)lds;
-        const uint32_t n16 = fa.hot_bytes >> 4;
+        const uint32_t n16 = fap->hot_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
     }
-    if (threadIdx.x == 0) cam_view_fill(s_cam, a);
     __syncthreads();
-    const DNode2 *nodes2 = (const DNode2 *)(lds + fa.off_nodes2);
-    const DBvhNode *leaves = (const DBvhNode *)(lds + fa.off_leaves);
-    unsigned short *tstack = (unsigned short *)(lds + fa.off_tstack) + threadIdx.x; /* [level * BLOCK] */
-    const DSphere *spheres = (const DSphere *)(lds + fa.off_spheres);
-    const DLambert *lambert = (const DLambert *)(lds + fa.off_lambert);
-    const DMetal *metal = (const DMetal *)(lds + fa.off_metal);
-    const DDielectric *dielectric = (const DDielectric *)(lds + fa.off_diel);
-    const DLambert *dlight = (const DLambert *)(lds + fa.off_dlight);
-    const DLambert *isotropic = (const DLambert *)(lds + fa.off_iso);
-    const DSolid *solid = (const DSolid *)(lds + fa.off_solid);
-    const DChecker *checker = (const DChecker *)(lds + fa.off_checker);
+    if (threadIdx.x == 0) cam_view_fill(s_cam, s_fa.r);
+    __syncthreads();
+    const FastArgs &L = s_fa;
+    const DNode2 *nodes2 = (const DNode2 *)(lds + BU_U(L.off_nodes2));
+    const DBvhNode *leaves = (const DBvhNode *)(lds + BU_U(L.off_leaves));
+    unsigned short *tstack = (unsigned short *)(lds + BU_U(L.off_tstack)) + threadIdx.x; /* [level * BLOCK] */
+    const DSphere *spheres = (const DSphere *)(lds + BU_U(L.off_spheres));
+    const DLambert *lambert = (const DLambert *)(lds + BU_U(L.off_lambert));
+    const DMetal *metal = (const DMetal *)(lds + BU_U(L.off_metal));
+    const DDielectric *dielectric = (const DDielectric *)(lds + BU_U(L.off_diel));
+    const DLambert *dlight = (const DLambert *)(lds + BU_U(L.off_dlight));
+    const DLambert *isotropic = (const DLambert *)(lds + BU_U(L.off_iso));
+    const DSolid *solid = (const DSolid *)(lds + BU_U(L.off_solid));
+    const DChecker *checker = (const DChecker *)(lds + BU_U(L.off_checker));
 
-    const int node_first = fa.node_first, node_end = fa.node_first + fa.node_count;
-    const int th_s = fa.th_s, th_l = fa.th_l, t_keep = fa.t_keep;
-    const int spp = a.sqrt_spp * a.sqrt_spp;
-    const unsigned total_q = (unsigned)fa.tiles_total * 64u;
+    const int node_first = BU_I(L.node_first), node_end = node_first + BU_I(L.node_count);
+    const int th_s = BU_I(L.th_s), th_l = BU_I(L.th_l), t_keep = BU_I(L.t_keep);
+    const int sqrt_spp = BU_I(L.r.sqrt_spp), bounce_limit = BU_I(L.r.bounce_limit);
+    const float bg_x = BU_F(L.r.background.x), bg_y = BU_F(L.r.background.y), bg_z = BU_F(L.r.background.z);
+    const int spp = sqrt_spp * sqrt_spp;
+    const unsigned total_q = (unsigned)BU_I(L.tiles_total) * 64u;
 
     /* per-lane state */
     int state = ST_S, kind = K_NEWPIX;
@@ -353,13 +417,17 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     uint32_t node = 0;     /* T: own-tree node; L: leaf record */
     int sp = 0, flags = 0; /* pending far children; FL_TIE / FL_REF */
     V3 final_value = mk(0, 0, 0);
-    StackEntry stack_deep[MORT_MAX_BOUNCE_LIMIT]; /* private overflow, touched only by paths deeper than the LDS part */
+    /* bounce-stack levels below the LDS part: [level - DL][lane of the launch] in HBM, one coalesced 1 KB row per wave and level, touched
+     * only by paths deeper than the LDS part (a private array is scratch memory sized for the deepest path in every lane) */
+    float4 *stack_deep = BU_P(L.deep) + ((size_t)blockIdx.x * BLOCK + threadIdx.x);
+    const size_t deep_stride = (size_t)gridDim.x * BLOCK;
     /* bit i set: bounce level i is a dielectric scatter, whose entry (k = (1,1,1), 1/pdf = 1) unwinds as
      * final = 0 + 1*((1,1,1)*final) = 0 + final exactly -- such levels are neither stored nor loaded */
     unsigned long long ident_mask = 0ull;
-    float4 *stack_lds = (float4 *)(lds + fa.off_stack);
-    const int DL = fa.stack_lds_depth;
+    float4 *stack_lds = (float4 *)(lds + BU_U(L.off_stack));
+    const int DL = BU_I(L.stack_lds_depth);
 #ifdef MORT_PROFILE_STATES
+    unsigned long long *const counters_p = fap->r.counters;
     unsigned long long prof[6] = {0, 0, 0, 0, 0, 0}; /* steps/lanes for T, L, S (wave-uniform) */
     unsigned long long prof_truns = 0;
     unsigned long long profc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* cycles in T, L, S, scheduler; S parts: shade, finish, newpix, setup */
@@ -367,10 +435,11 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
 #define PROFS0() do { ps0 = __builtin_readcyclecounter(); } while (0)
 #define PROFS(i) do { ps1 = __builtin_readcyclecounter(); profc[i] += ps1 - ps0; ps0 = ps1; } while (0)
     unsigned long long pt0 = __builtin_readcyclecounter(), pt1;
+    const unsigned long long prof_r0 = __builtin_amdgcn_s_memrealtime();
 #define PROF(i, lanes) do { prof[2 * (i)] += 1; prof[2 * (i) + 1] += (unsigned long long)(lanes); } while (0)
     unsigned long long profb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* S branches: steps entered, lanes: metal, dielectric, lambertian, finish, get_ray, unwind iterations */
 #define PROFB(i) do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { \
-        atomicAdd(&a.counters[18 + 2 * (i)], 1ull); atomicAdd(&a.counters[19 + 2 * (i)], (unsigned long long)__popcll(m_)); } } while (0)
+        atomicAdd(&counters_p[18 + 2 * (i)], 1ull); atomicAdd(&counters_p[19 + 2 * (i)], (unsigned long long)__popcll(m_)); } } while (0)
 #define PROFC(i) do { pt1 = __builtin_readcyclecounter(); profc[i] += pt1 - pt0; pt0 = pt1; } while (0)
 #else
 #define PROF(i, lanes) do { } while (0)
@@ -385,12 +454,19 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
      * state runs next, so its chain advances at the pace of a wave that carries it alone; the other lanes advance
      * whenever they share its state. */
     int leader = -1;
-    for (;;) {
+    /* Loop shape: the scheduler and the two traversal states form an INNER loop in which only (state, node, sp, kind, closest, best, flags)
+     * change; the shade step, which rewrites the whole per-lane state, is the outer loop's body.  As one flat loop hipcc gave every step
+     * -- box steps included -- a round trip of some fifty register copies at the common join of the three branches */
+    bool running = true;
+    while (running) {
+      int nS = 0;
+      for (;;) {
         const unsigned long long mT = __ballot(state == ST_T);
         const unsigned long long mL = __ballot(state == ST_L);
         const unsigned long long mS = __ballot(state == ST_S);
-        if ((mT | mL | mS) == 0ull) break;
-        const int nT = __popcll(mT), nL = __popcll(mL), nS = __popcll(mS);
+        if ((mT | mL | mS) == 0ull) { running = false; break; }
+        const int nT = __popcll(mT), nL = __popcll(mL);
+        nS = __popcll(mS);
         int pick;
         if (nS >= th_s) pick = ST_S;
         else if (nL >= th_l) pick = ST_L;
@@ -462,7 +538,10 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                 } else { state = ST_S; kind = K_SHADE; }
             }
             PROFC(1);
-        } else {
+        } else break;
+      }
+      if (!running) break;
+        {
             /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
             PROF(2, nS);
             PROFS0();
@@ -473,15 +552,15 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                     bool need_ref = flags != 0;
                     if (!need_ref && best >= 0) need_ref = !slab_check(leaves[best >> 16], ray, orr, closest);
                     if (need_ref) { /* rare (about one segment in 10^5): the reference's own walk */
-                        atomicAdd(&a.counters[3], 1ull);
-                        const RefHit h = reference_walk(a.sc.nodes, node_first, node_end, spheres, ray.o.x, ray.o.y, ray.o.z,
+                        atomicAdd(&fap->r.counters[3], 1ull);
+                        const RefHit h = reference_walk(fap->r.sc.nodes, node_first, node_end, spheres, ray.o.x, ray.o.y, ray.o.z,
                                                         ray.d.x, ray.d.y, ray.d.z, ray.tm, ray_a);
                         best = h.best; closest = h.closest;
                     }
                 REGION("S:hitrecord");
                     if (best >= 0) best &= 0x7fff;
                     if (best < 0) { /* camera.cuh:154-158 */
-                        final_value = a.background;
+                        final_value = mk(bg_x, bg_y, bg_z);
                         kind = K_FINISH;
                     } else {
                         const DSphere sp = spheres[best];
@@ -537,7 +616,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                                     } else break;
                                 }
                                 if (!resolved) { /* image / noise / error pattern: tables stay in HBM */
-                                    const V3Ret c = texture_value_uv(&a.sc, tex, outward.x, outward.y, outward.z, p.x, p.y, p.z);
+                                    const V3Ret c = texture_value_uv(&fap->r.sc, tex, outward.x, outward.y, outward.z, p.x, p.y, p.z);
                                     attenuation = mk(c.x, c.y, c.z);
                                 }
                             }
@@ -566,7 +645,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                             if (mtype == MORT_MAT_DIFFUSE_LIGHT && front_face) {
                                 const DLambert m = dlight[midx];
                                 if (m.tex == 0) emission = mk(m.r, m.g, m.b);
-                                else { const V3Ret c = texture_value_uv(&a.sc, m.tex, outward.x, outward.y, outward.z, p.x, p.y, p.z); emission = mk(c.x, c.y, c.z); }
+                                else { const V3Ret c = texture_value_uv(&fap->r.sc, m.tex, outward.x, outward.y, outward.z, p.x, p.y, p.z); emission = mk(c.x, c.y, c.z); }
                             }
                             final_value = emission;
                             kind = K_FINISH;
@@ -574,11 +653,12 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                 REGION("S:stackstore");
                         if (kind == K_SHADE) {
                             if (!((ident_mask >> iter) & 1ull)) {
-                                if (iter < DL) { float4 e4; e4.x = e.kx; e4.y = e.ky; e4.z = e.kz; e4.w = e.rp; stack_lds[iter * BLOCK + threadIdx.x] = e4; }
-                                else stack_deep[iter] = e;
+                                float4 e4; e4.x = e.kx; e4.y = e.ky; e4.z = e.kz; e4.w = e.rp;
+                                if (iter < DL) stack_lds[iter * BLOCK + threadIdx.x] = e4;
+                                else stack_deep[(size_t)(iter - DL) * deep_stride] = e4;
                             }
                             iter++;
-                            if (iter >= a.bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
+                            if (iter >= bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
                         }
                     }
                 }
@@ -596,8 +676,8 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                             const int lvl = 63 - __builtin_clzll(todo);
                             todo &= ~(1ull << lvl);
                             StackEntry e;
-                            if (lvl < DL) { const float4 e4 = stack_lds[lvl * BLOCK + threadIdx.x]; e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w; }
-                            else e = stack_deep[lvl];
+                            const float4 e4 = (lvl < DL) ? stack_lds[lvl * BLOCK + threadIdx.x] : stack_deep[(size_t)(lvl - DL) * deep_stride];
+                            e.kx = e4.x; e.ky = e4.y; e.kz = e4.z; e.rp = e4.w;
                             const V3 t = vmul(mk(e.kx, e.ky, e.kz), final_value);
                             final_value = vadd(mk(0, 0, 0), vscale(e.rp, t));
                         }
@@ -608,22 +688,22 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                     s_ij++;
                     bool more; /* samples left in this work item (SUB: one stratum row) */
                     if constexpr (SUB) {
-                        more = (s_ij & 0xffff) != a.sqrt_spp;
+                        more = (s_ij & 0xffff) != sqrt_spp;
                     } else {
-                        if ((s_ij & 0xffff) == a.sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
-                        more = (s_ij >> 16) < a.sqrt_spp;
+                        if ((s_ij & 0xffff) == sqrt_spp) s_ij = (s_ij & ~0xffff) + 0x10000;
+                        more = (s_ij >> 16) < sqrt_spp;
                     }
                     if (more) {
                         kind = K_NEWSAMPLE;
                     } else {
-                        pixel_write<PROBE, SUB>(&fa, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        pixel_write<PROBE, SUB>(fap, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
                         kind = K_NEWPIX;
                     }
                 }
                 REGION("S:newpix");
                 PROFS(5);
                 if (kind == K_NEWPIX) {
-                    const PixelFetch pf = pixel_fetch<SUB>(&fa, total_q);
+                    const PixelFetch pf = pixel_fetch<SUB>(fap, total_q);
                     if (!pf.got) state = ST_DONE;
                     else {
                         xy = pf.xy; lofs = pf.lofs;
@@ -642,11 +722,11 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                 if (state != ST_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
                         PROFB(4);
-                        ray = get_ray(s_cam, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
+                        ray = get_ray(s_cam, xy & 0xffff, (xy >> 16) & 0x7fff, rng, s_ij & 0xffff, s_ij >> 16);
                         ray_time0 = ray.tm;
                         iter = 0;
                         kind = K_SHADE;
-                        if (a.bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
+                        if (bounce_limit <= 0) { final_value = mk(0, 0, 0); kind = K_FINISH; }
                     }
                 REGION("S:setup");
                     if (kind == K_SHADE) { /* start world::hit for the new ray */
@@ -670,7 +750,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                 REGION("S:end");
             /* pool empty (some lane found no pixel): follow the lane with the fewest samples done */
             if (DRAIN && __ballot(state == ST_DONE) != 0ull) {
-                unsigned key = (state <= ST_S) ? ((unsigned)((s_ij >> 16) * a.sqrt_spp + (s_ij & 0xffff)) << 6) | (threadIdx.x & 63u) : 0xffffffffu;
+                unsigned key = (state <= ST_S) ? ((unsigned)((s_ij >> 16) * sqrt_spp + (s_ij & 0xffff)) << 6) | (threadIdx.x & 63u) : 0xffffffffu;
                 for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)key, off); key = o < key ? o : key; }
                 leader = (key == 0xffffffffu) ? -1 : __builtin_amdgcn_readfirstlane((int)(key & 63u));
             }
@@ -680,10 +760,16 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     }
     if ((threadIdx.x & 63) == 0) {
 #ifdef MORT_PROFILE_STATES
-        for (int k = 0; k < 6; k++) atomicAdd(&a.counters[4 + k], prof[k]);
-        atomicAdd(&a.counters[30], prof_truns);
-        for (int k = 0; k < 4; k++) atomicAdd(&a.counters[10 + k], profc[k]);
-        for (int k = 4; k < 8; k++) atomicAdd(&a.counters[14 + k - 4], profc[k]);
+        for (int k = 0; k < 6; k++) atomicAdd(&counters_p[4 + k], prof[k]);
+        atomicAdd(&counters_p[30], prof_truns);
+        for (int k = 0; k < 4; k++) atomicAdd(&counters_p[10 + k], profc[k]);
+        for (int k = 4; k < 8; k++) atomicAdd(&counters_p[14 + k - 4], profc[k]);
+        /* MORT_WAVE_LINES=1: one record per wave (same columns as mega_gen.hip's, the M columns empty) */
+        if (fap->wave_log) {
+            unsigned long long *w = fap->wave_log + 16 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+            w[0] = blockIdx.x; w[1] = threadIdx.x >> 6; w[2] = __builtin_amdgcn_s_memrealtime() - prof_r0;
+            w[3] = prof[0]; w[4] = prof[2]; w[5] = 0; w[6] = prof[4]; w[7] = profc[0]; w[8] = profc[1]; w[9] = 0; w[10] = profc[2]; w[11] = profc[3];
+        }
         (void)profb;
 #endif
     }

@@ -61,37 +61,37 @@ __device__ __attribute__((noinline)) ScanHit scan_solids(const DScene *scp, int 
  * scene).  Now: the by-value parameter is never named; the kernarg segment is copied once into LDS (s_ga), every
  * wave-uniform value the state loop needs is moved from there into an SGPR (readfirstlane: the compiler can neither re-load nor
  * re-materialise it), and the rare out-of-line helpers get the kernarg segment's own address. */
-__device__ __forceinline__ int uni_i(int x) { return __builtin_amdgcn_readfirstlane(x); }
-__device__ __forceinline__ uint32_t uni_u(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-__device__ __forceinline__ float uni_f(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
-template <typename T> __device__ __forceinline__ T *uni_p(T *p) {
-    const unsigned long long v = (unsigned long long)p;
-    const uint32_t lo = uni_u((uint32_t)v), hi = uni_u((uint32_t)(v >> 32));
-    return (T *)(((unsigned long long)hi << 32) | (unsigned long long)lo);
-}
-
 /* primitive records that stay in HBM / L2 (worlds whose primitives do not fit in LDS): loaded as global dwordx4, not through a flat
  * pointer (a flat load counts on the LDS counter too, and the leaf step waits on LDS all the time) */
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef const v4f_t __attribute__((address_space(1))) *gv4_ptr;
-template <bool IN_LDS> __device__ __forceinline__ DSphere load_sphere(const DSphere *base, uint32_t idx) {
-    if (IN_LDS) return base[idx];
-    const gv4_ptr p = (gv4_ptr)(unsigned long long)(base + idx);
-    const v4f_t a = p[0], b = p[1];
+/* one primitive record as raw registers: a quad's 80 bytes (a..e) or a sphere's 32 (a, b) */
+struct PrimRec { v4f_t a, b, c, d, e; };
+template <bool IN_LDS> __device__ __forceinline__ PrimRec load_prim(const DSphere *spheres, const DQuad *quads, uint32_t e) {
+    PrimRec r;
+    const v4f_t z = {0.f, 0.f, 0.f, 0.f};
+    r.a = r.b = r.c = r.d = r.e = z;
+    if (GENT_QUAD(e)) {
+        if (IN_LDS) { const v4f_t *p = (const v4f_t *)(quads + GENT_IDX(e)); r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3]; r.e = p[4]; }
+        else { const gv4_ptr p = (gv4_ptr)(unsigned long long)(quads + GENT_IDX(e)); r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3]; r.e = p[4]; }
+    } else {
+        if (IN_LDS) { const v4f_t *p = (const v4f_t *)(spheres + GENT_IDX(e)); r.a = p[0]; r.b = p[1]; }
+        else { const gv4_ptr p = (gv4_ptr)(unsigned long long)(spheres + GENT_IDX(e)); r.a = p[0]; r.b = p[1]; }
+    }
+    return r;
+}
+__device__ __forceinline__ DSphere rec_sphere(const PrimRec &r) {
     DSphere s;
-    s.cx = a.x; s.cy = a.y; s.cz = a.z; s.radius = a.w; s.vx = b.x; s.vy = b.y; s.vz = b.z; s.mat = __float_as_uint(b.w);
+    s.cx = r.a.x; s.cy = r.a.y; s.cz = r.a.z; s.radius = r.a.w; s.vx = r.b.x; s.vy = r.b.y; s.vz = r.b.z; s.mat = __float_as_uint(r.b.w);
     return s;
 }
-template <bool IN_LDS> __device__ __forceinline__ DQuad load_quad(const DQuad *base, uint32_t idx) {
-    if (IN_LDS) return base[idx];
-    const gv4_ptr p = (gv4_ptr)(unsigned long long)(base + idx);
-    const v4f_t a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
+__device__ __forceinline__ DQuad rec_quad(const PrimRec &r) {
     DQuad q;
-    q.Q[0] = a.x; q.Q[1] = a.y; q.Q[2] = a.z; q.D = a.w;
-    q.u[0] = b.x; q.u[1] = b.y; q.u[2] = b.z; q.area = b.w;
-    q.v[0] = c.x; q.v[1] = c.y; q.v[2] = c.z; q.mat = __float_as_uint(c.w);
-    q.n[0] = d.x; q.n[1] = d.y; q.n[2] = d.z; q.pad0 = 0;
-    q.w[0] = e.x; q.w[1] = e.y; q.w[2] = e.z; q.pad1 = 0;
+    q.Q[0] = r.a.x; q.Q[1] = r.a.y; q.Q[2] = r.a.z; q.D = r.a.w;
+    q.u[0] = r.b.x; q.u[1] = r.b.y; q.u[2] = r.b.z; q.area = r.b.w;
+    q.v[0] = r.c.x; q.v[1] = r.c.y; q.v[2] = r.c.z; q.mat = __float_as_uint(r.c.w);
+    q.n[0] = r.d.x; q.n[1] = r.d.y; q.n[2] = r.d.z; q.pad0 = 0;
+    q.w[0] = r.e.x; q.w[1] = r.e.y; q.w[2] = r.e.z; q.pad1 = 0;
     return q;
 }
 
@@ -192,6 +192,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
     unsigned long long gp_steps[4] = {0, 0, 0, 0}, gp_lanes[4] = {0, 0, 0, 0}, gp_cyc[5] = {0, 0, 0, 0, 0}, gp_lprims = 0, gp_liters = 0;
     unsigned long long gp_sp[6] = {0, 0, 0, 0, 0, 0}, gps0 = 0, gps1; /* S parts: stack store, finish, new pixel, new ray, decode, shade */
     unsigned long long gpt0 = __builtin_readcyclecounter(), gpt1;
+    const unsigned long long gp_r0 = __builtin_amdgcn_s_memrealtime();
 #define GPROFS0() do { gps0 = __builtin_readcyclecounter(); } while (0)
 #define GPROFS(i) do { gps1 = __builtin_readcyclecounter(); gp_sp[i] += gps1 - gps0; gps0 = gps1; } while (0)
 #define GPROF(i, lanes) do { gp_steps[i] += 1; gp_lanes[i] += (unsigned long long)(lanes); } while (0)
@@ -202,19 +203,32 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
 #define GPROFS0() do { } while (0)
 #define GPROFS(i) do { } while (0)
 #endif
-    for (;;) {
+    /* Loop shape: the scheduler and the three search states (T, L, M) form an INNER loop in which only the search's own variables (state,
+     * node, sp, kind, closest, best, flags; M: the stream) change; the shade step, which rewrites the whole per-lane state, is the outer
+     * loop's body.  As one flat loop hipcc gave every step -- box steps included -- a round trip of some fifty register copies at the
+     * common join of the four branches (mega_bvh.h) */
+    bool running = true;
+    while (running) {
+      int nS = 0;
+      for (;;) {
         const unsigned long long mT = __ballot(state == G_T);
         const unsigned long long mL = __ballot(state == G_L);
         const unsigned long long mM = __ballot(state == G_M);
         const unsigned long long mS = __ballot(state == G_S);
-        if ((mT | mL | mM | mS) == 0ull) break;
-        const int nT = __popcll(mT), nL = __popcll(mL), nM = __popcll(mM), nS = __popcll(mS);
+        if ((mT | mL | mM | mS) == 0ull) { running = false; break; }
+        const int nT = __popcll(mT), nL = __popcll(mL), nM = __popcll(mM);
+        nS = __popcll(mS);
         int pick;
         if (nS >= th_s) pick = G_S;
         else if (nM >= th_m) pick = G_M;
         else if (nL >= th_l) pick = G_L;
         else if (nT > 0) pick = G_T;
         else pick = (nL >= nS && nL >= nM) ? G_L : (nM >= nS ? G_M : G_S);
+        /* a wave that holds a priority pixel (one of the frame's longest chains, or any pixel once the pool is empty) runs the state THAT lane
+         * is in: its chain advances at the pace of a wave that carries it alone, the other lanes advance whenever they share its state */
+        const unsigned long long mP = __ballot(xy < 0 && state != G_DONE);
+        const int leader = mP != 0ull ? __ffsll((long long)mP) - 1 : -1;
+        if (leader >= 0) pick = __builtin_amdgcn_readlane(state, leader);
         GPROFC(4);
 
         if (pick == G_T) {
@@ -243,6 +257,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                     }
                 }
                 keep = __popcll(__ballot(state == G_T));
+                if (leader >= 0) keep = (__builtin_amdgcn_readlane(state, leader) == G_T) ? 64 : 0;
             } while (keep >= t_keep);
             GPROFC(0);
         } else if (pick == G_L) {
@@ -252,23 +267,25 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
             uint32_t pos = 0;
             int cnt = 0;
             if (state == G_L) { const uint32_t rec = leaves[node]; pos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
-            /* the record of the NEXT primitive is requested before this one is tested: with the primitives in HBM / L2 (the final scene's
-             * 2 401 quads do not fit in LDS) a leaf is otherwise a chain of dependent load -> test -> load */
-            uint32_t e_next = 0;
-            DSphere sp_next; DQuad qd_next;
-            sp_next.cx = sp_next.cy = sp_next.cz = sp_next.radius = sp_next.vx = sp_next.vy = sp_next.vz = 0; sp_next.mat = 0;
-            qd_next = load_quad<PRIMS_LDS>(quads, 0);
-            if (cnt > 0) { e_next = entries[pos]; if (GENT_QUAD(e_next)) qd_next = load_quad<PRIMS_LDS>(quads, GENT_IDX(e_next)); else sp_next = load_sphere<PRIMS_LDS>(spheres, GENT_IDX(e_next)); }
+            /* the record of the NEXT primitive is requested before this one is tested (with the primitives in HBM / L2 -- the final scene's
+             * 2 401 quads do not fit in LDS -- a leaf is otherwise a chain of dependent load -> test -> load); two primitives per trip through
+             * two sets of registers, so that nothing is copied from "next" to "current" */
+            uint32_t e0 = 0, e1 = 0;
+            PrimRec r0, r1;
+            { const v4f_t z = {0.f, 0.f, 0.f, 0.f}; r0.a = r0.b = r0.c = r0.d = r0.e = z; r1 = r0; }
+            if (cnt > 0) { e0 = entries[pos]; r0 = load_prim<PRIMS_LDS>(spheres, quads, e0); }
             while (__ballot(cnt > 0) != 0ull) {
 #ifdef MORT_PROFILE_STATES
                 gp_liters++; gp_lprims += (unsigned long long)__popcll(__ballot(cnt > 0));
 #endif
                 if (cnt > 0) {
-                    const uint32_t e = e_next;
-                    const DSphere sp_cur = sp_next; const DQuad qd_cur = qd_next;
-                    if (cnt > 1) { e_next = entries[pos + 1]; if (GENT_QUAD(e_next)) qd_next = load_quad<PRIMS_LDS>(quads, GENT_IDX(e_next)); else sp_next = load_sphere<PRIMS_LDS>(spheres, GENT_IDX(e_next)); }
-                    gen_leaf_test_rec(lsc, chains, ranks, n_spheres, sp_cur, qd_cur, e, ray, ray_a, closest, best, flags);
-                    pos++; cnt--;
+                    if (cnt > 1) { e1 = entries[pos + 1]; r1 = load_prim<PRIMS_LDS>(spheres, quads, e1); }
+                    gen_leaf_test_rec(lsc, chains, ranks, n_spheres, rec_sphere(r0), rec_quad(r0), e0, ray, ray_a, closest, best, flags);
+                    if (cnt > 1) {
+                        if (cnt > 2) { e0 = entries[pos + 2]; r0 = load_prim<PRIMS_LDS>(spheres, quads, e0); }
+                        gen_leaf_test_rec(lsc, chains, ranks, n_spheres, rec_sphere(r1), rec_quad(r1), e1, ray, ray_a, closest, best, flags);
+                    }
+                    pos += 2; cnt -= 2;
                 }
             }
             if (state == G_L) {
@@ -296,7 +313,10 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 state = G_S; kind = K_SHADE;
             }
             GPROFC(2);
-        } else {
+        } else break;
+      }
+      if (!running) break;
+        {
             GPROF(3, nS);
             /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
             GPROFS0();
@@ -392,7 +412,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 GPROFS(1);
                 if (kind == K_NEWPIX) {
                     const PixelFetch pf = pixel_fetch<SUB>(&gap->f, total_q);
-                    if (!pf.got) state = G_DONE;
+                    if (!pf.got) { state = G_DONE; xy = 0; }
                     else {
                         xy = pf.xy; lofs = pf.lofs;
                         rng.d = pf.d; rng.v0 = pf.v0; rng.v1 = pf.v1; rng.v2 = pf.v2; rng.v3 = pf.v3; rng.v4 = pf.v4;
@@ -406,7 +426,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 GPROFS(2);
                 if (state != G_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
-                        ray = get_ray(s_cam, xy & 0xffff, (int)((unsigned)xy >> 16), rng, s_ij & 0xffff, s_ij >> 16);
+                        ray = get_ray(s_cam, xy & 0xffff, (xy >> 16) & 0x7fff, rng, s_ij & 0xffff, s_ij >> 16);
                         ray_time0 = ray.tm;
                         iter = 0;
                         kind = K_SHADE;
@@ -426,6 +446,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                     }
                 }
             }
+            /* pool empty (some lane found no pixel): every pixel still in this wave is a priority pixel from here on */
+            if (!SUB && __ballot(state == G_DONE) != 0ull && state != G_DONE) xy |= (int)0x80000000u;
             GPROFS(3);
             GPROFC(3);
         }
@@ -437,6 +459,14 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
         for (int k = 0; k < 5; k++) atomicAdd(&counters[12 + k], gp_cyc[k]);
         atomicAdd(&counters[17], gp_liters); atomicAdd(&counters[18], gp_lprims);
         for (int k = 0; k < 6; k++) atomicAdd(&counters[20 + k], gp_sp[k]);
+        /* MORT_WAVE_LINES=1 in the environment of a profile build: one record per wave -- when it ended (10 ns ticks after its start), its
+         * steps and the cycles it spent in each state; the waves that end last are the frame's tail (scripts/wave_lines.py) */
+        if (gap->f.wave_log) {
+            unsigned long long *w = gap->f.wave_log + 16 * ((size_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+            w[0] = blockIdx.x; w[1] = threadIdx.x >> 6; w[2] = __builtin_amdgcn_s_memrealtime() - gp_r0;
+            for (int k = 0; k < 4; k++) { w[3 + k] = gp_steps[k]; w[7 + k] = gp_cyc[k]; }
+            w[11] = gp_cyc[4];
+        }
     }
 #endif
 }

@@ -43,6 +43,8 @@ struct mort_ctx {
     size_t rgba_cap = 0, accum_cap = 0, segpx_cap = 0;
     void *d_deep = nullptr; /* state-machine megakernels: bounce-stack levels below the LDS part, [level][lane of the launch] */
     size_t deep_cap = 0;
+    void *d_wave_log = nullptr; /* profile builds, MORT_WAVE_LINES=1: 16 words per wave of the last state-machine launch */
+    size_t wave_log_cap = 0, wave_log_waves = 0;
     unsigned long long *d_counters = nullptr; /* [0] segments, [1] rng draws, [2] work counter */
     bool wave_ok = false; /* wavefront mode: one BVH over spheres as the whole world, hot blob fits LDS */
     /* BVH megakernel: its own LDS image (own tree, reference leaf records, spheres, material / texture tables) */

@@ -216,7 +216,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_substates); hipFree(c->d_vaccum);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
-    hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states); hipFree(c->d_deep);
+    hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states); hipFree(c->d_deep); hipFree(c->d_wave_log);
     if (c->h_live) hipHostFree(c->h_live);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -758,6 +758,20 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         if (grid < 1) grid = 1;
         lds_bytes_used = (int)lds_bytes;
         fast_kernel_used = (const void *)kern;
+        { /* bounce-stack levels that do not fit in LDS: [level - dl][lane of the launch] in HBM */
+            const int deep_levels = cam->bounce_limit > dl ? cam->bounce_limit - dl : 0;
+            int st_d = ensure_buf(c, &c->d_deep, &c->deep_cap, (size_t)(deep_levels > 0 ? deep_levels : 1) * (size_t)grid * (size_t)FB * sizeof(float4));
+            if (st_d != MORT_OK) return st_d;
+            fa.deep = (float4 *)c->d_deep;
+            fa.wave_log = nullptr;
+            if (std::getenv("MORT_WAVE_LINES")) { /* profile builds: 16 words per wave, read back by mort_hip_debug_wave_log */
+                c->wave_log_waves = (size_t)grid * (size_t)(FB / 64);
+                if (ensure_buf(c, &c->d_wave_log, &c->wave_log_cap, c->wave_log_waves * 16 * sizeof(unsigned long long)) == MORT_OK) {
+                    hipMemsetAsync(c->d_wave_log, 0, c->wave_log_waves * 16 * sizeof(unsigned long long), s);
+                    fa.wave_log = (unsigned long long *)c->d_wave_log;
+                }
+            }
+        }
         std::snprintf(kname, sizeof kname, "mega_bvh_kernel<%d, false, %s, %s>", FB, chain_bound ? "true" : "false", substream ? "true" : "false");
         /* ---- tile order: expensive tiles first (sub-stream launches: work items are a stratum row, 1/sqrt_spp of a pixel -- no long tail to order away) ---- */
         if (!substream && !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
@@ -825,6 +839,14 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             int st_d = ensure_buf(c, &c->d_deep, &c->deep_cap, (size_t)(deep_levels > 0 ? deep_levels : 1) * (size_t)grid * (size_t)FB * sizeof(float4));
             if (st_d != MORT_OK) return st_d;
             fa.deep = (float4 *)c->d_deep;
+            fa.wave_log = nullptr;
+            if (std::getenv("MORT_WAVE_LINES")) { /* profile builds: 16 words per wave, read back by mort_hip_debug_wave_log */
+                c->wave_log_waves = (size_t)grid * (size_t)(FB / 64);
+                if (ensure_buf(c, &c->d_wave_log, &c->wave_log_cap, c->wave_log_waves * 16 * sizeof(unsigned long long)) == MORT_OK) {
+                    hipMemsetAsync(c->d_wave_log, 0, c->wave_log_waves * 16 * sizeof(unsigned long long), s);
+                    fa.wave_log = (unsigned long long *)c->d_wave_log;
+                }
+            }
         }
         std::snprintf(kname, sizeof kname, substream ? "mega_gen_kernel<%d, %s, true>" : "mega_gen_kernel<%d, %s>", FB, ga.prims_in_lds ? "true" : "false");
         if (!substream && !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
@@ -836,6 +858,17 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             });
             if (st_o != MORT_OK) return st_o;
             if (stats) HIPCHK(c, hipEventRecord(c->ev0, s));
+            /* priority pixels (mega_bvh.h FastArgs): the head of the cost order, a few per wave.  A frame with a handful of pixels per lane
+             * ends when its longest pixel chain does (final scene 800x800: the fog ball's pixels run 8 x the mean), and a chain advances one
+             * segment per round of its wave: such a pixel must not share its wave with 63 others of its kind, and its wave must follow it */
+            int k_prio = 2;
+            { const char *kp = std::getenv("MORT_GEN_PRIO_LANES"); if (kp) k_prio = std::atoi(kp); }
+            if (k_prio > 0 && !substream) {
+                const long long waves = (long long)grid * (FB / 64);
+                long long pt = (waves * k_prio + 63) / 64;
+                if (pt > tiles / 4) pt = tiles / 4;
+                fa.prio_tiles = (int)pt; fa.prio_lanes = k_prio;
+            }
         }
         HIPCHK(c, mort_gen_launch(ga, FB, grid, lds_bytes, s));
         if (substream) {
@@ -935,6 +968,16 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         return fill(stats);
     }
     return MORT_OK;
+}
+
+/* diagnostic (not in include/mort_hip.h): the per-wave records of the last frame of a profile build run with MORT_WAVE_LINES=1 */
+extern "C" int mort_hip_debug_wave_log(mort_ctx *c, unsigned long long *out, size_t max_waves) {
+    if (!c || !out || !c->d_wave_log) return 0;
+    hipSetDevice(c->device);
+    quiesce(c);
+    const size_t n = c->wave_log_waves < max_waves ? c->wave_log_waves : max_waves;
+    if (hipMemcpy(out, c->d_wave_log, n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return (int)n;
 }
 
 extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum,
