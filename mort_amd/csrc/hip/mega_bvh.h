@@ -72,6 +72,8 @@ struct FastArgs {
      * their own cursor (next_q[1]), so that every wave holds at most a few of the frame's longest chains, and flagged: their wave runs
      * the state THEY are in next (PixelFetch.prio).  0 = none */
     int prio_tiles, prio_lanes;
+    int drain_rounds;           /* DRAIN kernels, once the pool is empty: 1 = run in rounds (every live lane one segment per shade step), 0 = follow the lane furthest behind */
+    int tile_key_sum;           /* 1 = order tiles by their segment sum (round 2), 0 = by their longest pixel */
     unsigned long long *wave_log; /* profile builds (-DMORT_PROFILE_STATES) with MORT_WAVE_LINES=1: 16 words per wave of the launch, else null */
 };
 
@@ -251,9 +253,11 @@ __device__ __attribute__((noinline)) void pixel_write(const FastArgs *fap, float
     if (c.x != c.x) c.x = 0.0f;
     if (c.y != c.y) c.y = 0.0f;
     if (c.z != c.z) c.z = 0.0f;
-    if (fa.tile_cost) {
+    if (fa.tile_cost) { /* the tile's key in the next frame's order: its LONGEST pixel (a frame with a few pixels per lane ends when its longest chains
+                         * do, so those must start first, and a tile with one long pixel among 63 short ones has a small sum), or the tile's sum */
         const int lyl = lofs / a.width, xl = lofs - lyl * a.width;
-        atomicAdd(&fa.tile_cost[(lyl >> 3) * fa.tiles_x + (xl >> 3)], segments);
+        unsigned *tc = &fa.tile_cost[(lyl >> 3) * fa.tiles_x + (xl >> 3)];
+        if (fa.tile_key_sum) atomicAdd(tc, segments); else atomicMax(tc, segments);
     }
     if (!PROBE) {
         if (a.accum) { a.accum[3 * lofs] = c.x; a.accum[3 * lofs + 1] = c.y; a.accum[3 * lofs + 2] = c.z; }
@@ -454,6 +458,8 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
      * state runs next, so its chain advances at the pace of a wave that carries it alone; the other lanes advance
      * whenever they share its state. */
     int leader = -1;
+    const bool drain_rounds = DRAIN && BU_I(L.drain_rounds) == 1;
+    const bool live_thresholds = BU_I(L.drain_rounds) == 3;
     /* Loop shape: the scheduler and the two traversal states form an INNER loop in which only (state, node, sp, kind, closest, best, flags)
      * change; the shade step, which rewrites the whole per-lane state, is the outer loop's body.  As one flat loop hipcc gave every step
      * -- box steps included -- a round trip of some fifty register copies at the common join of the three branches */
@@ -468,13 +474,15 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
         const int nT = __popcll(mT), nL = __popcll(mL);
         nS = __popcll(mS);
         int pick;
-        if (nS >= th_s) pick = ST_S;
-        else if (nL >= th_l) pick = ST_L;
+        int e_s = th_s, e_l = th_l; /* batch thresholds as shares of the wave's live lanes (mega_gen.hip) */
+        if (live_thresholds) { const int live = nT + nL + nS; e_s = (th_s * live + 63) >> 6; e_l = (th_l * live + 63) >> 6; }
+        if (nS >= e_s) pick = ST_S;
+        else if (nL >= e_l) pick = ST_L;
         else if (nT > 0) pick = ST_T;
         else pick = (nL >= nS) ? ST_L : ST_S;
         if (DRAIN && leader >= 0) {
-            const int ls = __builtin_amdgcn_readlane(state, leader);
-            if (ls <= ST_S) pick = ls;
+            if (drain_rounds) pick = nT > 0 ? ST_T : nL > 0 ? ST_L : ST_S; /* rounds: every live lane advances one segment per shade step (mega_gen.hip) */
+            else { const int ls = __builtin_amdgcn_readlane(state, leader); if (ls <= ST_S) pick = ls; }
         }
         PROFC(3);
 
@@ -509,7 +517,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                 }
                 }
                 keep = __popcll(__ballot(state == ST_T));
-                if (DRAIN && leader >= 0) keep = (__builtin_amdgcn_readlane(state, leader) == ST_T) ? 64 : 0;
+                if (DRAIN && leader >= 0) keep = drain_rounds ? (keep > 0 ? 64 : 0) : (__builtin_amdgcn_readlane(state, leader) == ST_T) ? 64 : 0;
             } while (keep >= t_keep);
             PROFC(0);
         } else if (pick == ST_L) {

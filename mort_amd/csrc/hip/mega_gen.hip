@@ -61,40 +61,6 @@ __device__ __attribute__((noinline)) ScanHit scan_solids(const DScene *scp, int 
  * scene).  Now: the by-value parameter is never named; the kernarg segment is copied once into LDS (s_ga), every
  * wave-uniform value the state loop needs is moved from there into an SGPR (readfirstlane: the compiler can neither re-load nor
  * re-materialise it), and the rare out-of-line helpers get the kernarg segment's own address. */
-/* primitive records that stay in HBM / L2 (worlds whose primitives do not fit in LDS): loaded as global dwordx4, not through a flat
- * pointer (a flat load counts on the LDS counter too, and the leaf step waits on LDS all the time) */
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-typedef const v4f_t __attribute__((address_space(1))) *gv4_ptr;
-/* one primitive record as raw registers: a quad's 80 bytes (a..e) or a sphere's 32 (a, b) */
-struct PrimRec { v4f_t a, b, c, d, e; };
-template <bool IN_LDS> __device__ __forceinline__ PrimRec load_prim(const DSphere *spheres, const DQuad *quads, uint32_t e) {
-    PrimRec r;
-    const v4f_t z = {0.f, 0.f, 0.f, 0.f};
-    r.a = r.b = r.c = r.d = r.e = z;
-    if (GENT_QUAD(e)) {
-        if (IN_LDS) { const v4f_t *p = (const v4f_t *)(quads + GENT_IDX(e)); r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3]; r.e = p[4]; }
-        else { const gv4_ptr p = (gv4_ptr)(unsigned long long)(quads + GENT_IDX(e)); r.a = p[0]; r.b = p[1]; r.c = p[2]; r.d = p[3]; r.e = p[4]; }
-    } else {
-        if (IN_LDS) { const v4f_t *p = (const v4f_t *)(spheres + GENT_IDX(e)); r.a = p[0]; r.b = p[1]; }
-        else { const gv4_ptr p = (gv4_ptr)(unsigned long long)(spheres + GENT_IDX(e)); r.a = p[0]; r.b = p[1]; }
-    }
-    return r;
-}
-__device__ __forceinline__ DSphere rec_sphere(const PrimRec &r) {
-    DSphere s;
-    s.cx = r.a.x; s.cy = r.a.y; s.cz = r.a.z; s.radius = r.a.w; s.vx = r.b.x; s.vy = r.b.y; s.vz = r.b.z; s.mat = __float_as_uint(r.b.w);
-    return s;
-}
-__device__ __forceinline__ DQuad rec_quad(const PrimRec &r) {
-    DQuad q;
-    q.Q[0] = r.a.x; q.Q[1] = r.a.y; q.Q[2] = r.a.z; q.D = r.a.w;
-    q.u[0] = r.b.x; q.u[1] = r.b.y; q.u[2] = r.b.z; q.area = r.b.w;
-    q.v[0] = r.c.x; q.v[1] = r.c.y; q.v[2] = r.c.z; q.mat = __float_as_uint(r.c.w);
-    q.n[0] = r.d.x; q.n[1] = r.d.y; q.n[2] = r.d.z; q.pad0 = 0;
-    q.w[0] = r.e.x; q.w[1] = r.e.y; q.w[2] = r.e.z; q.pad1 = 0;
-    return q;
-}
-
 #ifndef MORT_GEN_WAVES_512
 #define MORT_GEN_WAVES_512 2
 #endif
@@ -208,6 +174,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
      * loop's body.  As one flat loop hipcc gave every step -- box steps included -- a round trip of some fifty register copies at the
      * common join of the four branches (mega_bvh.h) */
     bool running = true;
+    bool draining = false; /* wave-uniform: some lane of this wave found the pixel pool empty */
+    const int drain_mode = uni_i(L.drain_mode);
     while (running) {
       int nS = 0;
       for (;;) {
@@ -219,16 +187,35 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
         const int nT = __popcll(mT), nL = __popcll(mL), nM = __popcll(mM);
         nS = __popcll(mS);
         int pick;
-        if (nS >= th_s) pick = G_S;
-        else if (nM >= th_m) pick = G_M;
-        else if (nL >= th_l) pick = G_L;
+        /* the batch thresholds are shares of the wave's LIVE lanes (drain_mode 3): once the pool is empty and lanes retire, fixed counts
+         * are never reached and the steps degenerate to whoever happens to wait (the frame's last waves ran 1.6 shade steps per segment) */
+        int e_s = th_s, e_m = th_m, e_l = th_l;
+        if (drain_mode == 3) { const int live = nT + nL + nM + nS; e_s = (th_s * live + 63) >> 6; e_m = (th_m * live + 63) >> 6; e_l = (th_l * live + 63) >> 6; }
+        if (nS >= e_s) pick = G_S;
+        else if (nM >= e_m) pick = G_M;
+        else if (nL >= e_l) pick = G_L;
         else if (nT > 0) pick = G_T;
         else pick = (nL >= nS && nL >= nM) ? G_L : (nM >= nS ? G_M : G_S);
-        /* a wave that holds a priority pixel (one of the frame's longest chains, or any pixel once the pool is empty) runs the state THAT lane
-         * is in: its chain advances at the pace of a wave that carries it alone, the other lanes advance whenever they share its state */
-        const unsigned long long mP = __ballot(xy < 0 && state != G_DONE);
-        const int leader = mP != 0ull ? __ffsll((long long)mP) - 1 : -1;
-        if (leader >= 0) pick = __builtin_amdgcn_readlane(state, leader);
+        /* Once the pool is empty (draining, wave-uniform) throughput no longer matters to this wave, only when its longest chain ends, and a
+         * chain advances one segment per shade step it takes part in.  With the throughput thresholds the last lanes of a wave drift out of
+         * phase (the frame's last waves ran 1.6 shade steps per segment of their longest pixel): from here on the wave runs in ROUNDS -- box
+         * steps until no lane is at a node, leaf steps until none is at a leaf, media, and the shade step only when every live lane waits for
+         * it -- so every live lane advances one segment per round.
+         * drain_mode 1 (measured, not the default): follow ONE lane (priority pixels, FastArgs.prio_lanes) instead. */
+        int leader = -1;
+        if (draining) {
+            if (drain_mode == 1) {
+                const unsigned long long mP = __ballot(xy < 0 && state != G_DONE);
+                leader = mP != 0ull ? __ffsll((long long)mP) - 1 : -1;
+                if (leader >= 0) pick = __builtin_amdgcn_readlane(state, leader);
+            } else if (drain_mode == 2) {
+                pick = nT > 0 ? G_T : nL > 0 ? G_L : nM > 0 ? G_M : G_S;
+            }
+        } else if (drain_mode == 1) {
+            const unsigned long long mP = __ballot(xy < 0 && state != G_DONE);
+            leader = mP != 0ull ? __ffsll((long long)mP) - 1 : -1;
+            if (leader >= 0) pick = __builtin_amdgcn_readlane(state, leader);
+        }
         GPROFC(4);
 
         if (pick == G_T) {
@@ -258,6 +245,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 }
                 keep = __popcll(__ballot(state == G_T));
                 if (leader >= 0) keep = (__builtin_amdgcn_readlane(state, leader) == G_T) ? 64 : 0;
+                else if (draining && drain_mode == 2) keep = keep > 0 ? 64 : 0; /* rounds: until no lane is at a node */
             } while (keep >= t_keep);
             GPROFC(0);
         } else if (pick == G_L) {
@@ -446,8 +434,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                     }
                 }
             }
-            /* pool empty (some lane found no pixel): every pixel still in this wave is a priority pixel from here on */
-            if (!SUB && __ballot(state == G_DONE) != 0ull && state != G_DONE) xy |= (int)0x80000000u;
+            /* pool empty (some lane found no pixel) */
+            if (!SUB && !draining && __ballot(state == G_DONE) != 0ull) draining = true;
+            if (draining && drain_mode == 1 && state != G_DONE) xy |= (int)0x80000000u; /* every pixel still here is a priority pixel */
             GPROFS(3);
             GPROFC(3);
         }

@@ -528,6 +528,7 @@ static int prepare_tile_order(mort_ctx *c, const mort_camera *cam, const RenderA
         pa.r.states = c->d_probe_states; pa.r.sqrt_spp = 1; pa.r.recip_sqrt_spp = 1.0f; pa.r.pixel_samples_scale = 1.0f;
         pa.r.accum = nullptr; pa.r.seg_px = nullptr;
         pa.tile_order = nullptr; pa.tile_cost = c->d_tile_cost;
+        { const char *tk = std::getenv("MORT_TILE_KEY"); pa.tile_key_sum = (tk && std::strcmp(tk, "sum") == 0) ? 1 : 0; }
         HIPCHK(c, launch_probe(pa));
         HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
         c->cost_key = key;
@@ -536,6 +537,7 @@ static int prepare_tile_order(mort_ctx *c, const mort_camera *cam, const RenderA
     HIPCHK(c, mort_tile_sort_desc(c->d_tile_cost, c->d_tile_keys, c->d_tile_iota, c->d_tile_order, c->d_sort_tmp, c->sort_tmp_bytes, tiles, s));
     HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
     fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost;
+    { const char *tk = std::getenv("MORT_TILE_KEY"); fa.tile_key_sum = (tk && std::strcmp(tk, "sum") == 0) ? 1 : 0; }
     fa.gen_tiles = grid * (FB / 64); /* one tile's worth of slots per wave in flight */
     fa.spread_shift = chain_bound ? 0 : 6; /* measured: whole tiles while lanes refill several times, single pixels otherwise */
     { const char *sp = std::getenv("MORT_SPREAD_SHIFT"); if (sp) fa.spread_shift = std::atoi(sp); }
@@ -715,6 +717,8 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
              * compiled without spills (<= 512 threads; one rank of 4 at 1200x675: 81 ms vs 90 ms with 768) */
             for (int k = (px_per_lane < 1.5 && !substream) ? 1 : 0; k < 4; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; }
         }
+        fa.drain_rounds = 0; /* DRAIN kernels follow the lane furthest behind (round 2); measured alternatives: 2 = rounds, 3 = thresholds as shares of the live lanes */
+        { const char *dm = std::getenv("MORT_BVH_DRAIN"); if (dm) fa.drain_rounds = std::atoi(dm) == 2 ? 1 : std::atoi(dm) == 3 ? 3 : 0; }
         void (*kern)(const FastArgs) = nullptr, (*kern_probe)(const FastArgs) = nullptr;
         /* chain-bound partition (about one pixel per lane or fewer): drain mode + spread fetches (mega_bvh.h) */
         bool chain_bound = px_per_lane < 1.5 && !substream;
@@ -812,6 +816,8 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         if (FB != 1024 && FB != 768 && FB != 512 && FB != 256) FB = 256;
         /* swept on the final scene, 800x800x100 (scripts/th_sweep.py, 180 settings): 373 ms here vs 449 ms with the BVH kernel's (40,24,12) and m = 24 */
         fa.th_s = 28; fa.th_l = 20; fa.t_keep = 4; ga.th_m = 56;
+        ga.drain_mode = 3; /* thresholds as shares of the live lanes; measured alternatives: 0 = fixed counts, 1 = follow one lane, 2 = rounds */
+        { const char *dm = std::getenv("MORT_GEN_DRAIN"); if (dm) ga.drain_mode = std::atoi(dm); }
         { const char *th = std::getenv("MORT_GEN_THRESHOLDS"); /* "s,l,k,m" */
           if (th) { int s_ = 0, l_ = 0, k_ = 0, m_ = 0; if (std::sscanf(th, "%d,%d,%d,%d", &s_, &l_, &k_, &m_) == 4) { fa.th_s = s_; fa.th_l = l_; fa.t_keep = k_; ga.th_m = m_; } } }
         const uint32_t tstack_off = (c->gen_bytes + 15u) & ~15u;
@@ -861,9 +867,9 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             /* priority pixels (mega_bvh.h FastArgs): the head of the cost order, a few per wave.  A frame with a handful of pixels per lane
              * ends when its longest pixel chain does (final scene 800x800: the fog ball's pixels run 8 x the mean), and a chain advances one
              * segment per round of its wave: such a pixel must not share its wave with 63 others of its kind, and its wave must follow it */
-            int k_prio = 2;
+            int k_prio = 0; /* measured, not the default: following one lane starves the other 63 of a tile whose pixels are all long */
             { const char *kp = std::getenv("MORT_GEN_PRIO_LANES"); if (kp) k_prio = std::atoi(kp); }
-            if (k_prio > 0 && !substream) {
+            if (k_prio > 0 && ga.drain_mode == 1 && !substream) {
                 const long long waves = (long long)grid * (FB / 64);
                 long long pt = (waves * k_prio + 63) / 64;
                 if (pt > tiles / 4) pt = tiles / 4;

@@ -23,6 +23,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "wave_gen.h"
@@ -82,35 +83,51 @@ __device__ __attribute__((noinline)) WScanHit wf_scan_solids(const DScene *scp, 
 }
 
 template <int BLOCK, bool PRIMS_LDS>
-__global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
+__global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    const GenArgs &ga = w.g;
-    const FastArgs &fa = ga.f;
-    const RenderArgs &a = fa.r;
+    /* launch arguments without private memory (mega_gen.hip): the by-value parameter is never named; the kernarg segment is copied into
+     * LDS, the loop's wave-uniform values are pinned in SGPRs, the out-of-line scan gets the segment's own address */
+    __shared__ WfGenArgs s_w;
+    const WfGenArgs *const wp = (const WfGenArgs *)__builtin_amdgcn_kernarg_segment_ptr();
     {
-        const uint4 *src = (const uint4 *)fa.hot_src;
+        const uint32_t *src = (const uint32_t *)wp;
+        uint32_t *dst = (uint32_t *)&s_w;
+        for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(WfGenArgs) / 4); i += BLOCK) dst[i] = src[i];
+    }
+    {
+        const uint4 *src = (const uint4 *)wp->g.f.hot_src;
         uint4 *dst = (uint4 *)lds;
-        const uint32_t n16 = fa.hot_bytes >> 4;
+        const uint32_t n16 = wp->g.f.hot_bytes >> 4;
         for (uint32_t i = threadIdx.x; i < n16; i += BLOCK) dst[i] = src[i];
     }
-    const int par = w.parity;
-    if (blockIdx.x == 0 && threadIdx.x == 0) w.cnt->front_count[par ^ 1] = 0; /* next front: its last reader was the previous wf_trav_gen */
+    const int par = wp->parity;
+    WfCounters *const wcnt = wp->cnt;
+    if (blockIdx.x == 0 && threadIdx.x == 0) wcnt->front_count[par ^ 1] = 0; /* next front: its last reader was the previous wf_trav_gen */
     __syncthreads();
-    const DNode2 *nodes2 = (const DNode2 *)(lds + ga.o_nodes);
-    const uint32_t *leaves = (const uint32_t *)(lds + ga.o_leaves);
-    const uint32_t *entries = (const uint32_t *)(lds + ga.o_entries);
-    const int *chains = (const int *)(lds + ga.o_chains);
-    unsigned short *tstack = (unsigned short *)(lds + fa.off_tstack) + threadIdx.x; /* [level * BLOCK] */
-    unsigned *stage = (unsigned *)(lds + w.t_stage) + (threadIdx.x >> 6) * (3 * WG_STAGE);
-    DScene lsc = a.sc;
-    lsc.xforms = (const DXform *)(lds + ga.o_xforms);
-    if (PRIMS_LDS) { lsc.spheres = (const DSphere *)(lds + ga.o_spheres); lsc.quads = (const DQuad *)(lds + ga.o_quads); }
+    const WfGenArgs &W = s_w;
+    const GenArgs &L = W.g;
+    const DNode2 *nodes2 = (const DNode2 *)(lds + uni_u(L.o_nodes));
+    const uint32_t *leaves = (const uint32_t *)(lds + uni_u(L.o_leaves));
+    const uint32_t *entries = (const uint32_t *)(lds + uni_u(L.o_entries));
+    const int *chains = (const int *)(lds + uni_u(L.o_chains));
+    unsigned short *tstack = (unsigned short *)(lds + uni_u(L.f.off_tstack)) + threadIdx.x; /* [level * BLOCK] */
+    unsigned *stage = (unsigned *)(lds + uni_u(W.t_stage)) + (threadIdx.x >> 6) * (3 * WG_STAGE);
+    DScene lsc; /* only what the leaf test reads: transform chains and primitives */
+    lsc.xforms = (const DXform *)(lds + uni_u(L.o_xforms));
+    if (PRIMS_LDS) { lsc.spheres = (const DSphere *)(lds + uni_u(L.o_spheres)); lsc.quads = (const DQuad *)(lds + uni_u(L.o_quads)); }
+    else { lsc.spheres = uni_p(L.f.r.sc.spheres); lsc.quads = uni_p(L.f.r.sc.quads); }
     const DSphere *spheres = lsc.spheres;
     const DQuad *quads = lsc.quads;
+    const uint32_t *ranks = uni_p(L.ranks);
+    const int n_spheres = uni_i(L.n_spheres);
+    const uint32_t root = uni_u(L.root);
+    const float g_x = uni_f(L.gx), g_y = uni_f(L.gy), g_z = uni_f(L.gz), g_R = uni_f(L.gR), g_mnear = uni_f(L.mnear), g_kmin = uni_f(L.kmin);
+    WfHit *const hits = uni_p(W.hits);
+    unsigned *const q_cls0 = uni_p(W.q_cls[0]), *const q_cls1 = uni_p(W.q_cls[1]), *const q_cls2 = uni_p(W.q_cls[2]);
     int staged[3] = {0, 0, 0};
     const int lane = threadIdx.x & 63;
-    const unsigned n_items = w.cnt->front_count[par];
-    const WfRay *front = w.q_ray[par];
+    const unsigned n_items = wcnt->front_count[par];
+    const WfRay *front = par ? uni_p(W.q_ray[1]) : uni_p(W.q_ray[0]);
 
     /* this wave's share of the front: 64-record batches wave_id, wave_id + n_waves, ... (strided, so every wave samples
      * the whole image: fronts are in pixel order and cost varies by region) */
@@ -118,7 +135,7 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
     unsigned next_batch = wave_id, b_base = 0;
     int b_cnt = 0, b_off = 0;
 
-    const int th_f = fa.th_s, th_l = fa.th_l, t_keep = fa.t_keep; /* scheduling thresholds (lanes), as in mega_gen.hip; F plays S's part */
+    const int th_f = uni_i(L.f.th_s), th_l = uni_i(L.f.th_l), t_keep = uni_i(L.f.t_keep); /* scheduling thresholds (lanes), as in mega_gen.hip; F plays S's part */
     int state = W_F;
     bool have = false;
     unsigned pos = 0;
@@ -131,9 +148,10 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
 #define WG_FLUSH(k) do { \
         if (staged[k] > 0) { \
             unsigned base_ = 0; \
-            if (lane == 0) base_ = atomicAdd(&w.cnt->cls_count[par][k], (unsigned)staged[k]); \
+            if (lane == 0) base_ = atomicAdd(&wcnt->cls_count[par][k], (unsigned)staged[k]); \
             base_ = __shfl(base_, 0); \
-            for (int i_ = lane; i_ < staged[k]; i_ += 64) w.q_cls[k][base_ + (unsigned)i_] = stage[(k) * WG_STAGE + i_]; \
+            unsigned *const qc_ = (k) == 0 ? q_cls0 : (k) == 1 ? q_cls1 : q_cls2; \
+            for (int i_ = lane; i_ < staged[k]; i_ += 64) qc_[base_ + (unsigned)i_] = stage[(k) * WG_STAGE + i_]; \
             staged[k] = 0; \
         } } while (0)
 
@@ -188,10 +206,19 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
             uint32_t lpos = 0;
             int cnt = 0;
             if (state == W_L) { const uint32_t rec = leaves[node]; lpos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
+            uint32_t e0 = 0, e1 = 0; /* two primitives per trip through two register sets, the next record requested before this one is tested (mega_gen.hip) */
+            PrimRec r0, r1;
+            { const v4f_t z = {0.f, 0.f, 0.f, 0.f}; r0.a = r0.b = r0.c = r0.d = r0.e = z; r1 = r0; }
+            if (cnt > 0) { e0 = entries[lpos]; r0 = load_prim<PRIMS_LDS>(spheres, quads, e0); }
             while (__ballot(cnt > 0) != 0ull) {
                 if (cnt > 0) {
-                    gen_leaf_test(lsc, chains, ga.ranks, ga.n_spheres, spheres, quads, entries[lpos], ray, ray_a, closest, best, flags);
-                    lpos++; cnt--;
+                    if (cnt > 1) { e1 = entries[lpos + 1]; r1 = load_prim<PRIMS_LDS>(spheres, quads, e1); }
+                    gen_leaf_test_rec(lsc, chains, ranks, n_spheres, rec_sphere(r0), rec_quad(r0), e0, ray, ray_a, closest, best, flags);
+                    if (cnt > 1) {
+                        if (cnt > 2) { e0 = entries[lpos + 2]; r0 = load_prim<PRIMS_LDS>(spheres, quads, e0); }
+                        gen_leaf_test_rec(lsc, chains, ranks, n_spheres, rec_sphere(r1), rec_quad(r1), e1, ray, ray_a, closest, best, flags);
+                    }
+                    lpos += 2; cnt -= 2;
                 }
             }
             if (state == W_L) {
@@ -209,7 +236,7 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
             const bool inF = (state == W_F);
             const bool fin = inF && have;
             if (fin && flags) { /* non-ordinary reciprocal / NaN root: the scan decides */
-                const WScanHit h = wf_scan_solids(&a.sc, ga.first_medium, (const int *)(fa.hot_src + ga.o_chains), ga.n_chains,
+                const WScanHit h = wf_scan_solids(&wp->g.f.r.sc, wp->g.first_medium, (const int *)(wp->g.f.hot_src + wp->g.o_chains), wp->g.n_chains,
                                                   ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tm);
                 best = h.best; closest = h.closest;
             }
@@ -217,7 +244,7 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
             int cls = -1;
             if (fin) {
                 WfHit h; h.t = closest; h.best = (int)best;
-                w.hits[pos] = h;
+                hits[pos] = h;
                 if (best == GBEST_NONE) cls = WC_FIN;
                 else {
                     const uint32_t mat = GENT_QUAD(best) ? quads[GENT_IDX(best)].mat : spheres[GENT_IDX(best)].mat;
@@ -258,11 +285,10 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
                     const WfRay rr = front[pos];
                     ray.o = mk(rr.ox, rr.oy, rr.oz); ray.d = mk(rr.dx, rr.dy, rr.dz); ray.tm = rr.tm;
                     ray_a = vlen2(ray.d);
-                    const bool ordinary = gen_ray_setup(ray, ga.gx, ga.gy, ga.gz, ga.gR, ga.mnear, ga.kmin, gr);
+                    const bool ordinary = gen_ray_setup(ray, g_x, g_y, g_z, g_R, g_mnear, g_kmin, gr);
                     closest = __builtin_inff(); best = GBEST_NONE; sp = 0;
                     flags = ordinary ? 0 : GFL_REF;
                     have = true;
-                    const uint32_t root = ga.root;
                     if (!ordinary || root == 0xffffu) state = W_F; /* retired at the next F step (the scan decides) */
                     else { node = root & 0x7fffu; state = (root & 0x8000u) ? W_L : W_T; }
                 }
@@ -275,10 +301,11 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs w) {
     WG_FLUSH(0); WG_FLUSH(1); WG_FLUSH(2);
 #ifdef MORT_PROFILE_STATES
     if (lane == 0) {
-        for (int k = 0; k < 3; k++) { atomicAdd(&a.counters[4 + k], pr_steps[k]); atomicAdd(&a.counters[8 + k], pr_lanes[k]); }
-        for (int k = 0; k < 4; k++) atomicAdd(&a.counters[12 + k], pr_cyc[k]);
-        atomicAdd(&a.counters[20], __builtin_amdgcn_s_memrealtime() - rt0); /* sum of wave lifetimes, 10 ns ticks */
-        atomicAdd(&a.counters[21], 1ull);
+        unsigned long long *const counters = wp->g.f.r.counters;
+        for (int k = 0; k < 3; k++) { atomicAdd(&counters[4 + k], pr_steps[k]); atomicAdd(&counters[8 + k], pr_lanes[k]); }
+        for (int k = 0; k < 4; k++) atomicAdd(&counters[12 + k], pr_cyc[k]);
+        atomicAdd(&counters[20], __builtin_amdgcn_s_memrealtime() - rt0); /* sum of wave lifetimes, 10 ns ticks */
+        atomicAdd(&counters[21], 1ull);
     }
 #endif
 #undef WG_FLUSH
@@ -429,13 +456,19 @@ __global__ void __launch_bounds__(256) wf_shade_gen(const WfGenArgs w) {
 /* ---- host side ---- */
 typedef void (*trav_kernel_t)(const WfGenArgs);
 static trav_kernel_t pick_trav(int block, bool prims_in_lds) {
+    if (block == 1024) return prims_in_lds ? wf_trav_gen<1024, true> : wf_trav_gen<1024, false>;
     if (block == 512) return prims_in_lds ? wf_trav_gen<512, true> : wf_trav_gen<512, false>;
     return prims_in_lds ? wf_trav_gen<256, true> : wf_trav_gen<256, false>;
 }
 static int trav_block_for(const GenArgs &ga) { /* the LDS image + per-wave staging must fit one CU's LDS */
     const size_t fixed = (size_t)ga.f.hot_bytes + 32;
     const size_t need512 = fixed + (size_t)MORT_OWN_STACK * 512 * 2 + (size_t)(512 / 64) * 3 * WG_STAGE * 4;
-    return need512 <= 150 * 1024 ? 512 : 256;
+    const size_t need1024 = fixed + (size_t)MORT_OWN_STACK * 1024 * 2 + (size_t)(1024 / 64) * 3 * WG_STAGE * 4;
+    int tb = need512 <= 150 * 1024 ? 512 : 256;
+    /* a big image (the final scene's 98 KB) admits one workgroup per CU: the kernel needs under 128 VGPRs, so that workgroup can bring four waves per SIMD */
+    if (need512 > 75 * 1024 && need1024 <= 158 * 1024) tb = 1024;
+    if (const char *e = std::getenv("MORT_WAVE_TRAV_BLOCK")) { const int v = std::atoi(e); if (v == 256 || v == 512 || (v == 1024 && need1024 <= 158 * 1024)) tb = v; }
+    return tb;
 }
 const void *mort_wave_gen_trav_kernel(bool prims_in_lds, int *block) {
     if (block) *block = 512;
