@@ -63,7 +63,7 @@ struct __attribute__((aligned(16))) DNode2 {
 #define MORT_OWN_MAX_DEPTH 15
 /* unified tree (scene_compile.h build_unified): at most this many primitives per leaf; an entry names one primitive */
 #ifndef MORT_GEN_LEAF_MAX
-#define MORT_GEN_LEAF_MAX 4
+#define MORT_GEN_LEAF_MAX 3 /* measured on the final scene (leaves of 3 / 4 / 6): 320 / 353 / 394 ms at 800x800x100, 189 / 198 / 214 ms at 1920x1080x49 */
 #endif
 #define GENT(kind, chain, idx) (((uint32_t)(kind) << 31) | ((uint32_t)(chain) << 24) | (uint32_t)(idx))
 #define GENT_QUAD(e) ((e) >> 31)

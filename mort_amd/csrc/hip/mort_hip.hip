@@ -306,7 +306,7 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
         const size_t lds_part = gb.size();
         const size_t o_ranks = place(gb, o.g_ranks); /* HBM only: read when two hits have equal t */
 #ifndef MORT_GEN_IMAGE_MAX
-#define MORT_GEN_IMAGE_MAX (100 * 1024)
+#define MORT_GEN_IMAGE_MAX (124 * 1024) /* + traversal stacks of 768 threads (24 KB) + the launch arguments: one workgroup per CU */
 #endif
         if (lds_part <= MORT_GEN_IMAGE_MAX) {
             HIPCHK(c, hipMalloc(&c->d_gen, gb.size()));
@@ -744,12 +744,14 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         const uint32_t tstack_off = (c->fast_bytes + 15u) & ~15u; /* traversal stacks: [MORT_OWN_STACK][thread] u16 */
         const uint32_t stack_off = tstack_off + (uint32_t)MORT_OWN_STACK * (uint32_t)FB * 2u;
         fa.off_tstack = tstack_off;
-        const int groups_per_cu = 768 / FB; /* keep 12 waves per CU */
-        uint32_t static_lds = 256; /* the kernel's own __shared__ objects come out of the same 160 KB */
-        { hipFuncAttributes fattr; if (hipFuncGetAttributes(&fattr, (const void *)kern) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 255) & ~(size_t)255); }
-        int dl = (int)(((160u * 1024u - static_lds) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
+        uint32_t static_lds = 1024; /* the kernel's own __shared__ objects come out of the same 160 KB */
+        { hipFuncAttributes fattr; if (hipFuncGetAttributes(&fattr, (const void *)kern) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 1023) & ~(size_t)1023); }
+        int groups_per_cu = 768 / FB; /* keep 12 waves per CU */
+        while (groups_per_cu > 1 && (long long)(stack_off + static_lds) * groups_per_cu > 160ll * 1024) groups_per_cu--;
+        long long room = (160ll * 1024 - (long long)static_lds * groups_per_cu) / groups_per_cu - (long long)stack_off;
+        if (room < 0) { c->last_error = "BVH image does not fit one CU's LDS"; return MORT_ERR_CAPACITY; }
+        int dl = (int)(room / ((long long)FB * 16));
         if (dl > 12) dl = 12;
-        if (dl < 0) dl = 0;
         fa.off_stack = stack_off; fa.stack_lds_depth = dl;
         const size_t lds_bytes = (size_t)stack_off + (size_t)dl * FB * 16;
         HIPCHK(c, hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -810,9 +812,11 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         int FB = 768;
         { const char *fb_env = std::getenv("MORT_GEN_BLOCK_SIZE");
           if (fb_env && !substream) FB = std::atoi(fb_env);
-          else { /* 512 threads = 2 waves per SIMD: the state loop fits its 256-VGPR budget without spilling (at 3 waves it spills 44
-                  * registers and the final scene is 9 % slower); fewer pixels than lanes: 256-thread groups so every CU has work */
-                 FB = (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
+          else { /* the state loop needs 157 VGPRs and no scratch: 768 threads = 3 waves per SIMD when the frame has many pixels per lane (4096 x 4096:
+                  * 143 vs 181 ms with 512); with a handful of pixels per lane the frame ends with its longest pixel chains, whose rounds are faster
+                  * with two waves per SIMD (800 x 800: 359 vs 370 ms); fewer pixels than lanes: 256-thread groups so every CU has work */
+                 const double ppl = (double)lanes_wanted / ((double)c->num_cus * 768.0);
+                 FB = ppl >= 8.0 ? 768 : (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
         if (FB != 1024 && FB != 768 && FB != 512 && FB != 256) FB = 256;
         /* swept on the final scene, 800x800x100 (scripts/th_sweep.py, 180 settings): 373 ms here vs 449 ms with the BVH kernel's (40,24,12) and m = 24 */
         fa.th_s = 28; fa.th_l = 20; fa.t_keep = 4; ga.th_m = 56;
@@ -823,12 +827,15 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         const uint32_t tstack_off = (c->gen_bytes + 15u) & ~15u;
         const uint32_t stack_off = tstack_off + (uint32_t)MORT_OWN_STACK * (uint32_t)FB * 2u;
         fa.off_tstack = tstack_off;
-        const int groups_per_cu = (FB == 512 || FB == 1024) ? 1 : 768 / FB;
-        uint32_t static_lds = 512; /* the kernel's own __shared__ objects come out of the same 160 KB */
-        { hipFuncAttributes fattr; if (mort_gen_attributes(FB, ga.prims_in_lds != 0, &fattr, substream) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 255) & ~(size_t)255); }
-        int dl = (int)(((160u * 1024u - static_lds) / (uint32_t)groups_per_cu - stack_off) / ((uint32_t)FB * 16u));
+        uint32_t static_lds = 1024; /* the kernel's own __shared__ objects come out of the same 160 KB */
+        { hipFuncAttributes fattr; if (mort_gen_attributes(FB, ga.prims_in_lds != 0, &fattr, substream) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 1023) & ~(size_t)1023); }
+        /* workgroups per CU: as many as keep 12 waves per CU, but a big image (the final scene's 120 KB) admits one */
+        int groups_per_cu = (FB == 512 || FB == 1024) ? 1 : 768 / FB;
+        while (groups_per_cu > 1 && (long long)(stack_off + static_lds) * groups_per_cu > 160ll * 1024) groups_per_cu--;
+        long long room = (160ll * 1024 - (long long)static_lds * groups_per_cu) / groups_per_cu - (long long)stack_off;
+        if (room < 0) { c->last_error = "unified-tree image does not fit one CU's LDS"; return MORT_ERR_CAPACITY; }
+        int dl = (int)(room / ((long long)FB * 16));
         if (dl > 12) dl = 12;
-        if (dl < 0) dl = 0;
         { const char *de = std::getenv("MORT_GEN_DL"); if (de && std::atoi(de) < dl) dl = std::atoi(de); }
         fa.off_stack = stack_off; fa.stack_lds_depth = dl;
         const size_t lds_bytes = (size_t)stack_off + (size_t)dl * FB * 16;

@@ -8,7 +8,7 @@ sys.path.insert(0, ROOT)
 from mort_amd import host, hip, structs as S
 sid, width, spp = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 frames = int(sys.argv[4]) if len(sys.argv) > 4 else 2
-world, cam = host.build_scene(sid, width=width, spp=spp)
+world, cam = host.build_scene(sid, width=width, spp=spp, aspect=(1.0 if width == 4096 else 1.7777778 if width == 1920 else None))
 with hip.Context(0) as ctx:
     ctx.upload_world(world)
     ctx.rng_seed(S.DEFAULT_SEED, cam.image_width, cam.image_height)

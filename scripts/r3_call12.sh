@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 3, call 12: checkpoint -- the whole GPU suite, then the frame times of the five configurations' frames
+cd "$GRAFT_REPO_ROOT" || exit 1
+timeout -k 10 800 python -m pytest tests -m gpu -x -q > gpurun_out/r3l_pytest.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -3 gpurun_out/r3l_pytest.log
+[ $rc -eq 0 ] || exit 1
+b() { timeout -k 10 300 python bench.py --no-calib --cpu-spp 0 --no-throughput-line --steps 3 --warmup 1 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],1), 'ms', d['roofline']['kernel'], d['config']['workload'][:70])"; }
+b; b --scene 6 --width 800 --spp 1000; b --scene 8 --width 800 --spp 1000 --steps 2; b --scene 8 --width 1920 --aspect 1.7777778 --spp 49; b --scene 8 --width 4096 --aspect 1 --spp 4
+b --scene 8 --width 4096 --aspect 1 --spp 4 --mode wave; b --mode wave; b --scene 8 --width 800 --spp 100 --mode wave
+MORT_GEN_BLOCK_SIZE=768 b --scene 8 --width 1920 --aspect 1.7777778 --spp 49; MORT_GEN_BLOCK_SIZE=768 b --scene 8 --width 800 --spp 100; MORT_GEN_BLOCK_SIZE=512 b --scene 8 --width 800 --spp 100
+MORT_GEN_MIN_PRIMS=0 b --scene 6 --width 800 --spp 100; b --scene 6 --width 800 --spp 100
