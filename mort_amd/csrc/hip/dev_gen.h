@@ -17,9 +17,31 @@
 #define GCHAIN_MEDIUM 0x7fu /* best = GENT(0, GCHAIN_MEDIUM, item index): the hit is a constant medium */
 enum { GFL_REF = 2 }; /* the tree walk does not decide this ray: the scan does */
 
+/* the twelve planes of a node's two child boxes (dev_scene.h DNodeQ): plane = fmaf(q, step, origin), exactly as the builder checked it */
+struct GenBoxes { float x0min, x0max, y0min, y0max, z0min, z0max, x1min, x1max, y1min, y1max, z1min, z1max; uint32_t c0, c1; };
+DEV float gen_bits_float(uint32_t u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __uint_as_float(u);
+#else
+    float f; __builtin_memcpy(&f, &u, 4); return f;
+#endif
+}
+DEV GenBoxes gen_node_decode(float ox, float oy, float oz, uint32_t exps, uint32_t q0, uint32_t q1, uint32_t q2, uint32_t children) {
+    const float sx = gen_bits_float((exps & 0xffu) << 23), sy = gen_bits_float(((exps >> 8) & 0xffu) << 23), sz = gen_bits_float(((exps >> 16) & 0xffu) << 23);
+    GenBoxes b;
+    b.x0min = __builtin_fmaf((float)(q0 & 0xffu), sx, ox); b.x0max = __builtin_fmaf((float)((q0 >> 8) & 0xffu), sx, ox);
+    b.y0min = __builtin_fmaf((float)((q0 >> 16) & 0xffu), sy, oy); b.y0max = __builtin_fmaf((float)(q0 >> 24), sy, oy);
+    b.z0min = __builtin_fmaf((float)(q1 & 0xffu), sz, oz); b.z0max = __builtin_fmaf((float)((q1 >> 8) & 0xffu), sz, oz);
+    b.x1min = __builtin_fmaf((float)((q1 >> 16) & 0xffu), sx, ox); b.x1max = __builtin_fmaf((float)(q1 >> 24), sx, ox);
+    b.y1min = __builtin_fmaf((float)(q2 & 0xffu), sy, oy); b.y1max = __builtin_fmaf((float)((q2 >> 8) & 0xffu), sy, oy);
+    b.z1min = __builtin_fmaf((float)((q2 >> 16) & 0xffu), sz, oz); b.z1max = __builtin_fmaf((float)(q2 >> 24), sz, oz);
+    b.c0 = children & 0xffffu; b.c1 = children >> 16;
+    return b;
+}
+
 /* what a walk needs besides the scene tables */
 struct GenWalk {
-    const DNode2 *nodes; const uint32_t *leaves; const uint32_t *entries; const int *chains;
+    const DNodeQ *nodes; const uint32_t *entries; const int *chains;
     const uint32_t *ranks; /* scan-order rank of every primitive: [sphere index] then [n_spheres + quad index] (ties only) */
     int n_spheres;
     int n_chains; uint32_t root; int first_medium;
@@ -208,15 +230,15 @@ DEV bool gen_world_hit(const DScene &sc, const GenWalk &gw, const Ray &ray, Rng 
         uint32_t cur = gw.root;
         for (;;) {
             if (cur & 0x8000u) {
-                const uint32_t rec = gw.leaves[cur & 0x7fffu];
-                uint32_t pos = rec & 0xffffffu;
-                for (int cnt = (int)(rec >> 24); cnt > 0; cnt--, pos++)
+                uint32_t pos = GLEAF_FIRST(cur);
+                for (int cnt = (int)GLEAF_COUNT(cur); cnt > 0; cnt--, pos++)
                     gen_leaf_test(sc, gw.chains, gw.ranks, gw.n_spheres, sc.spheres, sc.quads, gw.entries[pos], ray, ray_a, closest, best, flags);
                 if (sp == 0) break;
                 cur = stack[--sp];
                 continue;
             }
-            const DNode2 nd = gw.nodes[cur & 0x7fffu];
+            const DNodeQ nq = gw.nodes[cur & 0x7fffu];
+            const GenBoxes nd = gen_node_decode(nq.ox, nq.oy, nq.oz, nq.exps, nq.q0, nq.q1, nq.q2, nq.children);
             float te0, te1;
             const bool m0 = gen_prune(nd.x0min, nd.x0max, nd.y0min, nd.y0max, nd.z0min, nd.z0max, gr, closest, te0);
             const bool m1 = gen_prune(nd.x1min, nd.x1max, nd.y1min, nd.y1max, nd.z1min, nd.z1max, gr, closest, te1);
@@ -225,9 +247,9 @@ DEV bool gen_world_hit(const DScene &sc, const GenWalk &gw, const Ray &ray, Rng 
                 cur = stack[--sp];
             } else if (!m0 && !m1) {
                 const bool first0 = te0 <= te1;
-                stack[sp++] = (unsigned short)(first0 ? nd.child1 : nd.child0);
-                cur = first0 ? nd.child0 : nd.child1;
-            } else cur = m0 ? nd.child1 : nd.child0;
+                stack[sp++] = (unsigned short)(first0 ? nd.c1 : nd.c0);
+                cur = first0 ? nd.c0 : nd.c1;
+            } else cur = m0 ? nd.c1 : nd.c0;
         }
     }
     if (flags) {

@@ -59,11 +59,28 @@ struct __attribute__((aligned(16))) DNode2 {
     uint32_t child0, child1;
     float e0, e1;
 };
+/* Node of the UNIFIED tree (scene_compile.h build_unified): 32 B = two ds_read_b128.  The boxes of its two children as 8-bit offsets
+ * from the node's own corner, in steps of a power of two per axis: plane = fmaf((float)q, step, origin).  The builder rounds every
+ * plane OUTWARD and checks it with the same fmaf, so a decoded box contains the child's padded box and every argument of
+ * build_unified's header holds for it (the walk only ever needs boxes that are not too small).  Half the bytes of DNode2: the final
+ * scene's 3 408 primitives get leaves of at most 2 primitives in fewer LDS bytes than leaves of 4 took before.
+ * A child reference is 16 bits: an inner node index, or 0x8000 | (primitives - 1) << 13 | first entry (a leaf is a run of entries). */
+struct __attribute__((aligned(16))) DNodeQ {
+    float ox, oy, oz;
+    uint32_t exps;     /* biased exponents of the steps: x | y << 8 | z << 16 */
+    uint32_t q0;       /* child 0: xlo | xhi << 8 | ylo << 16 | yhi << 24 */
+    uint32_t q1;       /* child 0: zlo | zhi << 8 | child 1: xlo << 16 | xhi << 24 */
+    uint32_t q2;       /* child 1: ylo | yhi << 8 | zlo << 16 | zhi << 24 */
+    uint32_t children; /* child 0 | child 1 << 16 */
+};
+#define GLEAF_FIRST(ref) ((ref) & 0x1fffu)
+#define GLEAF_COUNT(ref) ((((ref) >> 13) & 3u) + 1u)
 #define MORT_OWN_STACK 16 /* pending far children per lane kept in LDS; deeper walks use the reference walk */
 #define MORT_OWN_MAX_DEPTH 15
 /* unified tree (scene_compile.h build_unified): at most this many primitives per leaf; an entry names one primitive */
 #ifndef MORT_GEN_LEAF_MAX
-#define MORT_GEN_LEAF_MAX 3 /* measured on the final scene (leaves of 3 / 4 / 6): 320 / 353 / 394 ms at 800x800x100, 189 / 198 / 214 ms at 1920x1080x49 */
+#define MORT_GEN_LEAF_MAX 2 /* at most 4 (two bits of a leaf reference).  Measured on the final scene with 64-byte nodes (leaves of 3 / 4 / 6): 320 / 353 / 394 ms at
+                              * 800x800x100, 189 / 198 / 214 ms at 1920x1080x49; leaves of 2 need the 32-byte nodes to fit LDS */
 #endif
 #define GENT(kind, chain, idx) (((uint32_t)(kind) << 31) | ((uint32_t)(chain) << 24) | (uint32_t)(idx))
 #define GENT_QUAD(e) ((e) >> 31)

@@ -108,7 +108,7 @@ extern "C" int mort_hip_render_host(const mort_world *world, const mort_camera *
     }
     std::memset(&job.gw, 0, sizeof job.gw);
     if (job.tree) {
-        job.gw.nodes = o.g_nodes.data(); job.gw.leaves = o.g_leaves.data(); job.gw.entries = o.g_entries.data(); job.gw.chains = o.g_chains.data();
+        job.gw.nodes = o.g_nodes.data(); job.gw.entries = o.g_entries.data(); job.gw.chains = o.g_chains.data();
         job.gw.ranks = o.g_ranks.data(); job.gw.n_spheres = (int)o.spheres.size();
         job.gw.n_chains = (int)(o.g_chains.size() / 2); job.gw.root = o.g_root; job.gw.first_medium = o.g_first_medium;
         job.gw.gx = o.g_c[0]; job.gw.gy = o.g_c[1]; job.gw.gz = o.g_c[2]; job.gw.gR = o.g_R; job.gw.mnear = o.g_mnear; job.gw.kmin = o.g_kmin;

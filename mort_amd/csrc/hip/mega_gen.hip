@@ -87,8 +87,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
     __syncthreads();
     const GenArgs &L = s_ga;
     /* ---- wave-uniform values of the state loop, pinned in SGPRs ---- */
-    const DNode2 *nodes2 = (const DNode2 *)(lds + uni_u(L.o_nodes));
-    const uint32_t *leaves = (const uint32_t *)(lds + uni_u(L.o_leaves));
+    const DNodeQ *nodes2 = (const DNodeQ *)(lds + uni_u(L.o_nodes));
     const uint32_t *entries = (const uint32_t *)(lds + uni_u(L.o_entries));
     const int *chains = (const int *)(lds + uni_u(L.o_chains));
     unsigned short *tstack = (unsigned short *)(lds + uni_u(L.f.off_tstack)) + threadIdx.x; /* [level * BLOCK] */
@@ -226,12 +225,13 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 for (int rep = 0; rep < MORT_T_UNROLL; rep++) {
                     GPROF(0, __popcll(__ballot(state == G_T)));
                     if (state == G_T) {
-                        const float4 *np = (const float4 *)(nodes2 + node);
-                        const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                        const uint4 *np = (const uint4 *)(nodes2 + node); /* two ds_read_b128: corner + steps, 12 plane offsets + children */
+                        const uint4 na = np[0], nb = np[1];
+                        const GenBoxes nd = gen_node_decode(__uint_as_float(na.x), __uint_as_float(na.y), __uint_as_float(na.z), na.w, nb.x, nb.y, nb.z, nb.w);
                         float te0, te1;
-                        const bool m0 = gen_prune(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, gr, closest, te0);
-                        const bool m1 = gen_prune(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, gr, closest, te1);
-                        const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                        const bool m0 = gen_prune(nd.x0min, nd.x0max, nd.y0min, nd.y0max, nd.z0min, nd.z0max, gr, closest, te0);
+                        const bool m1 = gen_prune(nd.x1min, nd.x1max, nd.y1min, nd.y1max, nd.z1min, nd.z1max, gr, closest, te1);
+                        const uint32_t c0 = nd.c0, c1 = nd.c1;
                         const bool both = !m0 && !m1, none = m0 && m1;
                         const bool first0 = te0 <= te1;
                         uint32_t next = both ? (first0 ? c0 : c1) : (m0 ? c1 : c0);
@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
              *      (sphere::hit objects.cuh:60-77, quad::hit :190-215 under translate / rotate_y :268-278,334-366) ---- */
             uint32_t pos = 0;
             int cnt = 0;
-            if (state == G_L) { const uint32_t rec = leaves[node]; pos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
+            if (state == G_L) { pos = GLEAF_FIRST(node); cnt = (int)GLEAF_COUNT(node); } /* a leaf reference is a run of entries */
             /* the record of the NEXT primitive is requested before this one is tested (with the primitives in HBM / L2 -- the final scene's
              * 2 401 quads do not fit in LDS -- a leaf is otherwise a chain of dependent load -> test -> load); two primitives per trip through
              * two sets of registers, so that nothing is copied from "next" to "current" */
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                         flags = 0;
                     }
 #ifdef MORT_DEBUG_PRINT
-                    if (lofs == L.f.r.debug_lofs) printf("[gen %d seg %u] o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) tm %.9g -> best %08x t %.9g draws %u\n", lofs, segments,
+                    if ((lofs & 0x7fffffff) == L.f.r.debug_lofs) printf("[gen %d seg %u] o (%.9g %.9g %.9g) d (%.9g %.9g %.9g) tm %.9g -> best %08x t %.9g draws %u\n", lofs, segments,
                         ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z, ray.tm, best, closest, rng.draws);
 #endif
                     if (best == GBEST_NONE) { /* camera.cuh:154-158 */
@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                          * Makefile.)  The parity tests against the oracle are what guards this. */
                         const ShadeOut so = shade_hit(lsc, light_type, light_idx, ray, ray_time0, b, rng);
 #ifdef MORT_DEBUG_PRINT
-                        if (lofs == L.f.r.debug_lofs) printf("   shaded: done %d ident %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", (int)so.done, (int)so.ident, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
+                        if ((lofs & 0x7fffffff) == L.f.r.debug_lofs) printf("   shaded: done %d ident %d o (%.9g %.9g %.9g) d (%.9g %.9g %.9g)\n", (int)so.done, (int)so.ident, ray.o.x, ray.o.y, ray.o.z, ray.d.x, ray.d.y, ray.d.z);
 #endif
                         GPROFS(5);
                         if (so.done) { final_value = so.final_value; kind = K_FINISH; }
@@ -342,6 +342,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                                 float4 e4; e4.x = so.e.kx; e4.y = so.e.ky; e4.z = so.e.kz; e4.w = so.e.rp;
                                 if (iter < DL) stack_lds[iter * BLOCK] = e4;
                                 else stack_deep[(size_t)(iter - DL) * deep_stride] = e4;
+                                /* an entry that is not finite (1 / pdf with pdf = 0) turns even a zero into NaN at the unwind: remember it (bit 31 of lofs) */
+                                const float z = e4.x * 0.0f + e4.y * 0.0f + e4.z * 0.0f + e4.w * 0.0f;
+                                if (z != z) lofs |= (int)0x80000000u;
                             }
                             iter++;
                             if (iter >= bounce_limit) { final_value = mk(0, 0, 0); kind = K_FINISH; } /* camera.cuh:161-163 */
@@ -350,6 +353,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 }
                 GPROFS(0);
                 if (kind == K_FINISH) { /* unwind + accumulate (camera.cuh:165-173,190); see mega_bvh.h for the identity levels */
+                    /* A path that ends in exactly zero radiance -- the bounce limit, a miss of a black background, the back of a light -- unwinds to
+                     * exactly (+0, +0, +0) through finite entries: every level is 0 + rp * (k * (+-0)) = +0.  Most paths of the final scene and the
+                     * Cornell boxes end that way (the only radiance is the lamp's), and their levels below the LDS part sit in HBM: not read at all. */
+                    const bool zero_path = iter > 0 && lofs >= 0 &&
+                                           ((__float_as_uint(final_value.x) | __float_as_uint(final_value.y) | __float_as_uint(final_value.z)) & 0x7fffffffu) == 0u;
+                    if (zero_path) { final_value = mk(0, 0, 0); iter = 0; }
                     if (iter > 0) {
                         unsigned long long todo = ~ident_mask & (iter >= 64 ? ~0ull : ((1ull << iter) - 1ull));
                         if ((ident_mask >> (iter - 1)) & 1ull) final_value = vadd(mk(0, 0, 0), final_value);
@@ -391,9 +400,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                     if (more) {
                         kind = K_NEWSAMPLE;
                     } else {
-                        if constexpr (SUB) pixel_write<false, true>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
-                        else if (probe) pixel_write<true>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
-                        else pixel_write<false>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        if constexpr (SUB) pixel_write<false, true>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs & 0x7fffffff, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        else if (probe) pixel_write<true>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs & 0x7fffffff, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
+                        else pixel_write<false>(&gap->f, pixel_color.x, pixel_color.y, pixel_color.z, lofs & 0x7fffffff, segments, rng.draws, rng.d, rng.v0, rng.v1, rng.v2, rng.v3, rng.v4);
                         kind = K_NEWPIX;
                     }
                 }
@@ -414,6 +423,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 GPROFS(2);
                 if (state != G_DONE) {
                     if (kind == K_NEWSAMPLE) { /* camera.cuh:187-190 */
+                        lofs &= 0x7fffffff;
                         ray = get_ray(s_cam, xy & 0xffff, (xy >> 16) & 0x7fff, rng, s_ij & 0xffff, s_ij >> 16);
                         ray_time0 = ray.tm;
                         iter = 0;

@@ -286,7 +286,7 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
         std::vector<unsigned char> gb;
         GenArgs g;
         std::memset(&g, 0, sizeof g);
-        g.o_nodes = (uint32_t)place(gb, o.g_nodes); g.o_leaves = (uint32_t)place(gb, o.g_leaves); g.o_entries = (uint32_t)place(gb, o.g_entries);
+        g.o_nodes = (uint32_t)place(gb, o.g_nodes); g.o_leaves = g.o_nodes; g.o_entries = (uint32_t)place(gb, o.g_entries);
         g.o_chains = (uint32_t)place(gb, o.g_chains); g.o_xforms = (uint32_t)place(gb, o.xforms);
         g.o_items = (uint32_t)place(gb, o.items); g.o_subitems = (uint32_t)place(gb, o.subitems); g.o_media = (uint32_t)place(gb, o.media);
         g.o_lambert = (uint32_t)place(gb, o.lambert); g.o_metal = (uint32_t)place(gb, o.metal); g.o_diel = (uint32_t)place(gb, o.dielectric);

@@ -49,8 +49,7 @@ struct Compiled {
     /* this build's UNIFIED tree over every solid primitive of a world without reference BVHs (mega_gen.hip):
      * see build_unified() */
     bool g_ok = false;
-    std::vector<DNode2> g_nodes;
-    std::vector<uint32_t> g_leaves;  /* first entry | count << 24 */
+    std::vector<DNodeQ> g_nodes;     /* 32-byte nodes: child boxes as 8-bit offsets from the node's corner (dev_scene.h) */
     std::vector<uint32_t> g_entries; /* GENT(kind, chain id, index in spheres / quads) */
     std::vector<int> g_chains;       /* chain id -> (first, count) in xforms; id 0 = no transform */
     std::vector<uint32_t> g_ranks;   /* scan-order rank of spheres[i] at [i], of quads[i] at [n spheres + i] (equal-t ties) */
@@ -499,15 +498,14 @@ struct Compiler {
         box_out = u;
         if (depth > out.g_depth) out.g_depth = depth;
         const int left = MORT_OWN_MAX_DEPTH - depth; /* node levels left below this point */
-        if (n <= MORT_GEN_LEAF_MAX || left <= 0) {
-            if (n > 255) { fail(MORT_ERR_CAPACITY); return 0xffffu; }
-            const size_t leaf = out.g_leaves.size();
-            out.g_leaves.push_back((uint32_t)out.g_entries.size() | ((uint32_t)n << 24));
+        if (n <= MORT_GEN_LEAF_MAX || left <= 0) { /* a leaf is a run of entries: 0x8000 | (n - 1) << 13 | first entry */
+            if (n > 4 || out.g_entries.size() + (size_t)n > 0x2000u) { gen_too_big = true; return 0xffffu; }
+            const size_t first = out.g_entries.size();
             for (int i = lo; i < hi; i++) {
                 const GPrim &g = pr[ids[i]];
                 out.g_entries.push_back(GENT(g.kind == ITEM_QUADS ? 1u : 0u, (uint32_t)g.chain_id, (uint32_t)g.idx));
             }
-            return 0x8000u | (uint32_t)leaf;
+            return 0x8000u | ((uint32_t)(n - 1) << 13) | (uint32_t)first;
         }
         /* both halves must fit below: at most LEAF_MAX * 2^(left-1) primitives each */
         const long long cap = (long long)MORT_GEN_LEAF_MAX << (left - 1 < 40 ? left - 1 : 40);
@@ -530,20 +528,58 @@ struct Compiler {
         }
         std::stable_sort(ids.begin() + lo, ids.begin() + hi, [&](int a, int b) { return pr[a].wb.lo[bax] + pr[a].wb.hi[bax] < pr[b].wb.lo[bax] + pr[b].wb.hi[bax]; });
         const size_t me = out.g_nodes.size();
-        out.g_nodes.push_back(DNode2{});
+        out.g_nodes.push_back(DNodeQ{});
         Box b0, b1;
         const uint32_t c0 = gen_emit(pr, ids, lo, lo + bsplit, depth + 1, b0);
         const uint32_t c1 = gen_emit(pr, ids, lo + bsplit, hi, depth + 1, b1);
-        DNode2 nd;
-        nd.x0min = b0.lo[0]; nd.x0max = b0.hi[0]; nd.y0min = b0.lo[1]; nd.y0max = b0.hi[1]; nd.z0min = b0.lo[2]; nd.z0max = b0.hi[2];
-        nd.x1min = b1.lo[0]; nd.x1max = b1.hi[0]; nd.y1min = b1.lo[1]; nd.y1max = b1.hi[1]; nd.z1min = b1.lo[2]; nd.z1max = b1.hi[2];
-        nd.child0 = c0; nd.child1 = c1; nd.e0 = 0; nd.e1 = 0;
-        out.g_nodes[me] = nd;
+        if (gen_too_big) return 0xffffu;
+        out.g_nodes[me] = quantize_node(b0, b1, c0, c1);
         return (uint32_t)me;
+    }
+    bool gen_too_big = false; /* more entries than a leaf reference can address: no unified tree for this world */
+    /* the two child boxes as 8-bit offsets from the node's corner (dev_scene.h DNodeQ): every plane rounded outward and checked with the
+     * decoder's own arithmetic, fmaf((float)q, step, origin), so the device sees boxes that contain b0 and b1 */
+    static DNodeQ quantize_node(const Box &b0, const Box &b1, uint32_t c0, uint32_t c1) {
+        DNodeQ nd;
+        std::memset(&nd, 0, sizeof nd);
+        float org[3]; unsigned ex[3]; unsigned q[2][3][2];
+        for (int a = 0; a < 3; a++) {
+            org[a] = std::fmin(b0.lo[a], b1.lo[a]);
+            const double ext = (double)std::fmax(b0.hi[a], b1.hi[a]) - (double)org[a];
+            int k = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0)) : -126;
+            if (k < -126) k = -126;
+            if (k > 127) k = 127;
+            for (;;) { /* the step is 2^k; widen it until both boxes fit in 0..255 steps */
+                const float step = std::ldexp(1.0f, k);
+                bool ok = true;
+                for (int c = 0; c < 2 && ok; c++) {
+                    const Box &b = c ? b1 : b0;
+                    long long ql = (long long)std::floor(((double)b.lo[a] - (double)org[a]) / (double)step);
+                    if (ql < 0) ql = 0;
+                    if (ql > 255) ql = 255;
+                    while (ql > 0 && std::fmaf((float)ql, step, org[a]) > b.lo[a]) ql--;
+                    long long qh = (long long)std::ceil(((double)b.hi[a] - (double)org[a]) / (double)step);
+                    if (qh < 0) qh = 0;
+                    while (qh <= 255 && std::fmaf((float)qh, step, org[a]) < b.hi[a]) qh++;
+                    if (qh > 255 || std::fmaf((float)ql, step, org[a]) > b.lo[a]) { ok = false; break; }
+                    q[c][a][0] = (unsigned)ql; q[c][a][1] = (unsigned)qh;
+                }
+                if (ok || k >= 127) { ex[a] = (unsigned)(k + 127); break; }
+                k++;
+            }
+        }
+        nd.ox = org[0]; nd.oy = org[1]; nd.oz = org[2];
+        nd.exps = ex[0] | (ex[1] << 8) | (ex[2] << 16);
+        nd.q0 = q[0][0][0] | (q[0][0][1] << 8) | (q[0][1][0] << 16) | (q[0][1][1] << 24);
+        nd.q1 = q[0][2][0] | (q[0][2][1] << 8) | (q[1][0][0] << 16) | (q[1][0][1] << 24);
+        nd.q2 = q[1][1][0] | (q[1][1][1] << 8) | (q[1][2][0] << 16) | (q[1][2][1] << 24);
+        nd.children = (c0 & 0xffffu) | (c1 << 16);
+        return nd;
     }
     void build_unified() {
         out.g_ok = false;
-        out.g_nodes.clear(); out.g_leaves.clear(); out.g_entries.clear(); out.g_chains.clear(); out.g_ranks.clear();
+        out.g_nodes.clear(); out.g_entries.clear(); out.g_chains.clear(); out.g_ranks.clear();
+        gen_too_big = false;
         out.g_root = 0xffffu; out.g_depth = 0;
         out.g_chains.push_back(0); out.g_chains.push_back(0); /* id 0: no transform */
         std::vector<GPrim> pr;
@@ -581,7 +617,7 @@ struct Compiler {
             Box rb;
             out.g_root = gen_emit(pr, ids, 0, (int)pr.size(), 0, rb);
             if (out.status != MORT_OK) return;
-            if (out.g_nodes.size() > 0x7fff || out.g_leaves.size() > 0x7fff) return;
+            if (gen_too_big || out.g_nodes.size() > 0x7fff) return;
         }
         out.g_ok = true;
     }

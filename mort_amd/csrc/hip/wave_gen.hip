@@ -106,8 +106,7 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs) {
     __syncthreads();
     const WfGenArgs &W = s_w;
     const GenArgs &L = W.g;
-    const DNode2 *nodes2 = (const DNode2 *)(lds + uni_u(L.o_nodes));
-    const uint32_t *leaves = (const uint32_t *)(lds + uni_u(L.o_leaves));
+    const DNodeQ *nodes2 = (const DNodeQ *)(lds + uni_u(L.o_nodes));
     const uint32_t *entries = (const uint32_t *)(lds + uni_u(L.o_entries));
     const int *chains = (const int *)(lds + uni_u(L.o_chains));
     unsigned short *tstack = (unsigned short *)(lds + uni_u(L.f.off_tstack)) + threadIdx.x; /* [level * BLOCK] */
@@ -182,12 +181,13 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs) {
             do {
                 WGPROF(0, __popcll(__ballot(state == W_T)));
                 if (state == W_T) { /* both child boxes of one node (dev_gen.h gen_prune) */
-                    const float4 *np = (const float4 *)(nodes2 + node);
-                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                    const uint4 *np = (const uint4 *)(nodes2 + node); /* two ds_read_b128: corner + steps, 12 plane offsets + children */
+                    const uint4 na = np[0], nb = np[1];
+                    const GenBoxes nd = gen_node_decode(__uint_as_float(na.x), __uint_as_float(na.y), __uint_as_float(na.z), na.w, nb.x, nb.y, nb.z, nb.w);
                     float te0, te1;
-                    const bool m0 = gen_prune(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, gr, closest, te0);
-                    const bool m1 = gen_prune(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, gr, closest, te1);
-                    const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
+                    const bool m0 = gen_prune(nd.x0min, nd.x0max, nd.y0min, nd.y0max, nd.z0min, nd.z0max, gr, closest, te0);
+                    const bool m1 = gen_prune(nd.x1min, nd.x1max, nd.y1min, nd.y1max, nd.z1min, nd.z1max, gr, closest, te1);
+                    const uint32_t c0 = nd.c0, c1 = nd.c1;
                     const bool both = !m0 && !m1, none = m0 && m1;
                     const bool first0 = te0 <= te1;
                     uint32_t next = both ? (first0 ? c0 : c1) : (m0 ? c1 : c0);
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs) {
             WGPROF(1, nL);
             uint32_t lpos = 0;
             int cnt = 0;
-            if (state == W_L) { const uint32_t rec = leaves[node]; lpos = rec & 0xffffffu; cnt = (int)(rec >> 24); }
+            if (state == W_L) { lpos = GLEAF_FIRST(node); cnt = (int)GLEAF_COUNT(node); } /* a leaf reference is a run of entries */
             uint32_t e0 = 0, e1 = 0; /* two primitives per trip through two register sets, the next record requested before this one is tested (mega_gen.hip) */
             PrimRec r0, r1;
             { const v4f_t z = {0.f, 0.f, 0.f, 0.f}; r0.a = r0.b = r0.c = r0.d = r0.e = z; r1 = r0; }
