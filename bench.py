@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--scene", type=int, default=1, help="reference scene id 1..10 (default 1 = the headline workload)")
     ap.add_argument("--depth", type=int, default=None, help="bounce limit override")
     ap.add_argument("--aspect", type=float, default=None, help="aspect ratio override")
-    ap.add_argument("--profile-tag", default="r2/headline", help="profiles/<tag>_pmc_*.{json,csv}: counter figures quoted when the run is the profiled configuration")
+    ap.add_argument("--profile-tag", default="r3/headline", help="profiles/<tag>_pmc_*.{json,csv}: counter figures quoted when the run is the profiled configuration")
     ap.add_argument("--rows-per-block", type=int, default=8)
     ap.add_argument("--cpu-spp", type=int, default=4, help="spp of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all online cores")

@@ -518,6 +518,10 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                 }
                 keep = __popcll(__ballot(state == ST_T));
                 if (DRAIN && leader >= 0) keep = drain_rounds ? (keep > 0 ? 64 : 0) : (__builtin_amdgcn_readlane(state, leader) == ST_T) ? 64 : 0;
+                else if (keep > 0 && keep < t_keep) { /* few lanes left at nodes: hand control back only if another state has its batch together (mega_gen.hip) */
+                    const int wL = __popcll(__ballot(state == ST_L)), wS = __popcll(__ballot(state == ST_S));
+                    if (!(wS >= e_s || wL >= e_l)) keep = 64;
+                }
             } while (keep >= t_keep);
             PROFC(0);
         } else if (pick == ST_L) {

@@ -246,6 +246,12 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 keep = __popcll(__ballot(state == G_T));
                 if (leader >= 0) keep = (__builtin_amdgcn_readlane(state, leader) == G_T) ? 64 : 0;
                 else if (draining && drain_mode == 2) keep = keep > 0 ? 64 : 0; /* rounds: until no lane is at a node */
+                else if (keep > 0 && keep < t_keep) {
+                    /* few lanes are left at nodes: hand control back only if another state has its batch together -- otherwise the scheduler
+                     * would pick the box steps again (a fifth of the cycles of the frame's last waves went into such passes) */
+                    const int wL = __popcll(__ballot(state == G_L)), wM = __popcll(__ballot(state == G_M)), wS = __popcll(__ballot(state == G_S));
+                    if (!(wS >= e_s || wM >= e_m || wL >= e_l)) keep = 64;
+                }
             } while (keep >= t_keep);
             GPROFC(0);
         } else if (pick == G_L) {

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 if os.environ.get("TH_CHILD"):
     from mort_amd import host, hip, structs as S
-    world, cam = host.build_scene(int(sys.argv[1]), width=int(sys.argv[2]), spp=int(sys.argv[3]))
+    world, cam = host.build_scene(int(sys.argv[1]), width=int(sys.argv[2]), spp=int(sys.argv[3]), aspect=(1.7777778 if int(sys.argv[2]) == 1920 else None))
     with hip.Context(0) as ctx:
         ctx.upload_world(world); ctx.rng_seed(S.DEFAULT_SEED, cam.image_width, cam.image_height)
         mode = hip.MODE_WAVE if os.environ.get("TH_MODE") == "wave" else hip.MODE_MEGA
