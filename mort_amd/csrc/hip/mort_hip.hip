@@ -818,6 +818,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
                  const double ppl = (double)lanes_wanted / ((double)c->num_cus * 768.0);
                  FB = ppl >= 8.0 ? 768 : (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
         if (FB != 1024 && FB != 768 && FB != 512 && FB != 256) FB = 256;
+        if (substream && FB > 512) FB = 512; /* the non-parity launch is instantiated for 512- and 256-thread workgroups */
         /* swept on the final scene, 800x800x100 (scripts/th_sweep.py, 180 settings): 373 ms here vs 449 ms with the BVH kernel's (40,24,12) and m = 24 */
         fa.th_s = 28; fa.th_l = 20; fa.t_keep = 4; ga.th_m = 56;
         ga.drain_mode = 3; /* thresholds as shares of the live lanes; measured alternatives: 0 = fixed counts, 1 = follow one lane, 2 = rounds */
@@ -861,7 +862,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
                 }
             }
         }
-        std::snprintf(kname, sizeof kname, substream ? "mega_gen_kernel<%d, %s, true>" : "mega_gen_kernel<%d, %s>", FB, ga.prims_in_lds ? "true" : "false");
+        std::snprintf(kname, sizeof kname, substream ? "mega_gen_kernel<%d, %s, true>" : "mega_gen_kernel<%d, %s, false>", FB, ga.prims_in_lds ? "true" : "false"); /* as rocprofv3 prints it: <BLOCK, PRIMS_LDS, SUB> */
         if (!substream && !std::getenv("MORT_NO_TILE_ORDER") && tiles >= 4 * grid) {
             int st_o = prepare_tile_order(c, cam, a, fa, tiles, grid, FB, false, s, [&](const FastArgs &pa) {
                 GenArgs pg = ga;
