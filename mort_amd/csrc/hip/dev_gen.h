@@ -156,6 +156,37 @@ DEV void gen_leaf_test_rec(const DScene &sc, const int *chains, const uint32_t *
     }
 }
 
+/* The two halves of gen_leaf_test_rec, for the leaf loops that test TWO primitives per trip: the own roots of both are computed first, against the
+ * same closest_so_far (two independent instruction chains for a wave that is bound by the latency of one), then applied in entry order.  That is the
+ * sequential result: a primitive offers its near root if that lies in [t_min, t_max], else its far root; with the larger t_max a root in (new closest, old closest]
+ * may be offered where the sequential test offers none -- gen_apply_t refuses it, as the sequential range test would have -- and a root <= the new closest is
+ * offered by both.  NaN roots are accepted by both forms (every comparison with NaN is false) and flag the ray for the scan. */
+DEV float gen_prim_t(const DScene &sc, const int *chains, const DSphere &sp, const DQuad &qd, uint32_t e, const Ray &ray, float ray_a, float closest) {
+    const uint32_t cid = GENT_CHAIN(e);
+    Ray r = ray;
+    float ra = ray_a;
+    if (cid != 0) {
+        r = apply_chain(sc, ray, chains[2 * cid], chains[2 * cid + 1]);
+        ra = vlen2(r.d);
+    }
+    float t;
+    if (GENT_QUAD(e)) {
+        float al, be;
+        if (!quad_hit_t(qd, r, 0.001f, closest, t, al, be)) t = -1.0f;
+    } else {
+        t = gen_sphere_root(sp, r, ra, 0.001f, closest);
+    }
+    return t;
+}
+DEV void gen_apply_t(const uint32_t *ranks, int n_spheres, float t, uint32_t e, float &closest, uint32_t &best, int &flags) {
+    if (t != -1.0f && !(t > closest)) { /* accepted: t <= closest_so_far, or t is NaN */
+        if (!(t == t)) flags |= GFL_REF;
+        const bool tie = (t == closest) && (best != GBEST_NONE);
+        if (!tie || gen_rank(ranks, n_spheres, e) > gen_rank(ranks, n_spheres, best)) best = e;
+        closest = t;
+    }
+}
+
 /* world::hit's scan over the solids as the reference runs it (world.cuh:122-168 through the flattened items): the exact
  * answer for the rays the tree walk does not decide */
 DEV void gen_scan_solids(const DScene &sc, int first_medium, const int *chains, int n_chains, const Ray &r, float &closest, uint32_t &best) {

@@ -56,7 +56,7 @@ DEV ShadeOut shade_hit(const DScene &sc, int light_type, int light_idx, Ray &ray
         /* materials.cuh:38-44,182-188 + camera.cuh:115-145 */
         const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
         const DLambert m = lamb ? sc.lambert[midx] : sc.isotropic[midx];
-        const V3 attenuation = lambert_color(sc, m, rec.u, rec.v, rec.p);
+        const V3 attenuation = lambert_color_rec(sc, m, rec);
         Onb uvw;
         if (lamb) uvw = onb_from_w(rec.normal);
         V3 dir;
@@ -89,7 +89,7 @@ DEV ShadeOut shade_hit(const DScene &sc, int light_type, int light_idx, Ray &ray
     } else { /* diffuse_light (materials.cuh:151-163) or unknown tag: no scatter */
         V3 emission = mk(0, 0, 0);
         if (mtype == MORT_MAT_DIFFUSE_LIGHT && rec.front_face)
-            emission = lambert_color(sc, sc.dlight[midx], rec.u, rec.v, rec.p);
+            emission = lambert_color_rec(sc, sc.dlight[midx], rec);
         o.final_value = emission;
         o.done = true;
     }

@@ -37,6 +37,10 @@ struct HitRec { /* hit_record.cuh:10-19 */
     uint32_t mat;
     float t, u, v;
     bool front_face;
+    /* a sphere's (u, v) (objects.cuh:101-108: acos + atan2) is a pure function of its outward normal and only the image texture and the
+     * error pattern read it: resolve_hit keeps the normal (uv_sphere) and texture_value_rec computes u, v where they are read */
+    V3 on;
+    bool uv_sphere;
 };
 
 /* ---- transform chains (translate::hit / rotate_y::hit, objects.cuh:268-278,334-366) ---- */
@@ -311,6 +315,7 @@ DEV void sphere_uv(V3 p, float &u, float &v) { /* objects.cuh:101-108 */
 }
 DEV void resolve_hit(const DScene &sc, const Ray &rw, const Best &b, HitRec &rec) {
     const Ray r = apply_chain(sc, rw, b.chain_first, b.chain_count);
+    rec.on = mk(0, 0, 0); rec.uv_sphere = false;
     rec.t = b.t;
     rec.p = ray_at(r, b.t);
     if (b.kind == HIT_SPHERE) {
@@ -318,7 +323,7 @@ DEV void resolve_hit(const DScene &sc, const Ray &rw, const Best &b, HitRec &rec
         const V3 outward = vdiv(vsub(rec.p, sphere_center(s, r.tm)), s.radius);
         rec.front_face = vdot(r.d, outward) < 0;
         rec.normal = rec.front_face ? outward : vneg(outward);
-        sphere_uv(outward, rec.u, rec.v);
+        rec.on = outward; rec.uv_sphere = true; rec.u = 0; rec.v = 0;
         rec.mat = s.mat & 0x7fffffffu;
     } else if (b.kind == HIT_QUAD) {
         const DQuad q = sc.quads[b.prim];
@@ -435,6 +440,30 @@ DEV V3 texture_value(const DScene &sc, uint32_t tex, float u, float v, V3 p) { /
 DEV V3 lambert_color(const DScene &sc, const DLambert &m, float u, float v, V3 p) {
     if (m.tex == 0) return mk(m.r, m.g, m.b);
     return texture_value(sc, m.tex, u, v, p);
+}
+/* texture_value for a resolved hit: the same lookups, a sphere's (u, v) computed only by the texture kinds that read them */
+DEV V3 texture_value_rec(const DScene &sc, uint32_t tex, const HitRec &rec) {
+    for (int guard = 0; guard < 8; guard++) {
+        const int type = DREF_TYPE(tex), idx = DREF_IDX(tex);
+        if (type == MORT_TEXTURE_SOLID) { const DSolid s = sc.solid[idx]; return mk(s.r, s.g, s.b); }
+        if (type == MORT_TEXTURE_CHECKER) { /* textures.cuh:52-60 */
+            const DChecker c = sc.checker[idx];
+            const int xi = mort_f2i(mort_floorf(c.inv_scale * rec.p.x));
+            const int yi = mort_f2i(mort_floorf(c.inv_scale * rec.p.y));
+            const int zi = mort_f2i(mort_floorf(c.inv_scale * rec.p.z));
+            tex = ((xi + yi + zi) % 2 == 0) ? c.even : c.odd;
+            continue;
+        }
+        if (type == MORT_TEXTURE_NOISE) return noise_value(sc.noise, idx, rec.p);
+        break; /* image texture, or an unknown tag's error pattern: these read (u, v) */
+    }
+    float u = rec.u, v = rec.v;
+    if (rec.uv_sphere) sphere_uv(rec.on, u, v);
+    return texture_value(sc, tex, u, v, rec.p);
+}
+DEV V3 lambert_color_rec(const DScene &sc, const DLambert &m, const HitRec &rec) {
+    if (m.tex == 0) return mk(m.r, m.g, m.b);
+    return texture_value_rec(sc, m.tex, rec);
 }
 
 /* ---- light sampling (objects.cuh:110-145,217-235,488-504; pdf.cuh:60-80) ---- */

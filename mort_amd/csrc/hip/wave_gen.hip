@@ -213,11 +213,14 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs) {
             while (__ballot(cnt > 0) != 0ull) {
                 if (cnt > 0) {
                     if (cnt > 1) { e1 = entries[lpos + 1]; r1 = load_prim<PRIMS_LDS>(spheres, quads, e1); }
-                    gen_leaf_test_rec(lsc, chains, ranks, n_spheres, rec_sphere(r0), rec_quad(r0), e0, ray, ray_a, closest, best, flags);
-                    if (cnt > 1) {
-                        if (cnt > 2) { e0 = entries[lpos + 2]; r0 = load_prim<PRIMS_LDS>(spheres, quads, e0); }
-                        gen_leaf_test_rec(lsc, chains, ranks, n_spheres, rec_sphere(r1), rec_quad(r1), e1, ray, ray_a, closest, best, flags);
-                    }
+                    /* both own roots against the same closest_so_far (independent chains), then applied in entry order: dev_gen.h gen_prim_t */
+                    const uint32_t ea = e0, eb = e1;
+                    const float ta = gen_prim_t(lsc, chains, rec_sphere(r0), rec_quad(r0), ea, ray, ray_a, closest);
+                    float tb = -1.0f;
+                    if (cnt > 1) tb = gen_prim_t(lsc, chains, rec_sphere(r1), rec_quad(r1), eb, ray, ray_a, closest);
+                    if (cnt > 2) { e0 = entries[lpos + 2]; r0 = load_prim<PRIMS_LDS>(spheres, quads, e0); }
+                    gen_apply_t(ranks, n_spheres, ta, ea, closest, best, flags);
+                    gen_apply_t(ranks, n_spheres, tb, eb, closest, best, flags);
                     lpos += 2; cnt -= 2;
                 }
             }
