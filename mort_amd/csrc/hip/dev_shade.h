@@ -15,6 +15,12 @@
 
 #pragma clang fp contract(off)
 
+#if defined(MORT_SHADE_MARKS) && defined(__HIP_DEVICE_COMPILE__) /* comments in the ISA at the shade step's parts (static instruction counts) */
+#define SHMARK(name) asm volatile("; MARK " name)
+#else
+#define SHMARK(name) do { } while (0)
+#endif
+
 struct ShadeOut {
     bool done;         /* path ends here: final_value is the radiance of this segment (emission, or 0) */
     bool ident;        /* scatter whose stack entry is the identity (dielectric: k = (1,1,1), 1/pdf = 1) */
@@ -30,15 +36,19 @@ DEV ShadeOut shade_hit(const DScene &sc, int light_type, int light_idx, Ray &ray
     o.e.kx = o.e.ky = o.e.kz = o.e.rp = 1.0f;
     o.final_value = mk(0, 0, 0);
     HitRec rec;
+    SHMARK("resolve");
     resolve_hit(sc, ray, best, rec);
+    SHMARK("dispatch");
     const int mtype = DREF_TYPE(rec.mat), midx = DREF_IDX(rec.mat);
     if (mtype == MORT_MAT_METAL) { /* materials.cuh:73-84 */
+        SHMARK("metal");
         const DMetal m = sc.metal[midx];
         V3 reflected = reflect(ray.d, rec.normal);
         reflected = vadd(vunit(reflected), vscale(m.fuzz, random_unit_vector(rng)));
         ray.o = rec.p; ray.d = reflected; /* time stays r_in.time() */
         o.e.kx = 1.0f * m.r; o.e.ky = 1.0f * m.g; o.e.kz = 1.0f * m.b; o.e.rp = 1 / 1.0f;
     } else if (mtype == MORT_MAT_DIELECTRIC) { /* materials.cuh:107-130 */
+        SHMARK("dielectric");
         const DDielectric m = sc.dielectric[midx];
         const float refraction_ratio = rec.front_face ? m.inv_ior : m.ior;
         const V3 unit_direction = vunit(ray.d);
@@ -54,9 +64,11 @@ DEV ShadeOut shade_hit(const DScene &sc, int light_type, int light_idx, Ray &ray
         o.ident = true; /* entry (1,1,1), 1/pdf = 1 */
     } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
         /* materials.cuh:38-44,182-188 + camera.cuh:115-145 */
+        SHMARK("diffuse_texture");
         const bool lamb = (mtype == MORT_MAT_LAMBERTIAN);
         const DLambert m = lamb ? sc.lambert[midx] : sc.isotropic[midx];
         const V3 attenuation = lambert_color_rec(sc, m, rec);
+        SHMARK("diffuse_sample");
         Onb uvw;
         if (lamb) uvw = onb_from_w(rec.normal);
         V3 dir;
@@ -65,6 +77,7 @@ DEV ShadeOut shade_hit(const DScene &sc, int light_type, int light_idx, Ray &ray
         if (from_light) dir = light_random(sc, light_type, light_idx, rec.p, rng);
         else if (lamb) dir = onb_local(uvw, random_cosine_direction(rng));
         else dir = random_unit_vector(rng);
+        SHMARK("diffuse_pdf");
         /* srec.pdf_ptr->value(dir): cosine_pdf / sphere_pdf (pdf.cuh:29-32,45-49) */
         float mat_pdf;
         if (lamb) {
@@ -87,12 +100,14 @@ DEV ShadeOut shade_hit(const DScene &sc, int light_type, int light_idx, Ray &ray
         o.e.kx = scattering_pdf * attenuation.x; o.e.ky = scattering_pdf * attenuation.y; o.e.kz = scattering_pdf * attenuation.z;
         o.e.rp = 1 / pdf;
     } else { /* diffuse_light (materials.cuh:151-163) or unknown tag: no scatter */
+        SHMARK("emissive");
         V3 emission = mk(0, 0, 0);
         if (mtype == MORT_MAT_DIFFUSE_LIGHT && rec.front_face)
             emission = lambert_color_rec(sc, sc.dlight[midx], rec);
         o.final_value = emission;
         o.done = true;
     }
+    SHMARK("shade_end");
     return o;
 }
 

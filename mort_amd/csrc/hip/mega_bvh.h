@@ -4,10 +4,12 @@
  *
  * CDNA4 design (each point bit-identical to the reference's arithmetic):
  *
- *  - Scene in LDS.  The kernel's image of the scene (its own tree as 64-byte two-child nodes, the reference's
- *    leaf records, spheres, material and texture tables: 48 KB for Scene 1) is copied into LDS once per workgroup;
- *    a box step reads one node with four ds_read_b128.  The reference reads 4 SoA arrays + a 24-byte aabb from
- *    global memory per node (objects.cuh:728-731).
+ *  - Scene in LDS.  The kernel's image of the scene (its own tree as four-child nodes, a record per reference leaf
+ *    node with its one or two spheres by value, the leaf boxes, material and texture tables: 55 KB for Scene 1) is
+ *    copied into LDS once per workgroup; a box step reads one node with eight independent ds_read_b128, a leaf step
+ *    one record with five.  Node and record sizes are an ODD number of 16-byte pieces (144 B, 80 B): the lanes of a
+ *    wave read the same piece of different records, and only an odd stride spreads those over all LDS banks.
+ *    The reference reads 4 SoA arrays + a 24-byte aabb from global memory per node (objects.cuh:728-731).
  *
  *  - Per-lane state machine, wave-level scheduling.  Each lane owns one pixel
  *    and is in one of three states: T (at a tree node, both child boxes to test),
@@ -26,7 +28,7 @@
  *  - Own tree, near child first.  The reference walks its median-split tree left-first (objects.cuh:664-723), 41
  *    box tests per segment in Scene 1.  bvh_node::hit returns the closest accepted sphere hit; WHICH one that is
  *    depends on the walk only through the leaf nodes it refuses to enter.  So this kernel walks its own SAH tree
- *    over the reference's leaf nodes (13 two-box steps per segment), and proves per ray that the reference's walk
+ *    over the reference's leaf nodes (four boxes per step, nearest child next), and proves per ray that the reference's walk
  *    would have returned the same sphere -- or else repeats the ray with the reference's walk:
  *      * leaf records keep the reference leaf box bit for bit, inner boxes are exact unions, so aabb::hit
  *        (aabb.cuh:37-59) passing on a leaf implies it passes on every box above it, in either tree (rounding is
@@ -46,12 +48,13 @@
 
 #include "dev_render.h"
 
+
 struct FastArgs {
     RenderArgs r;
     const unsigned char *hot_src; /* device copy of the kernel's LDS image */
     uint32_t hot_bytes;
-    uint32_t off_nodes2, off_leaves, off_spheres, off_lambert, off_metal, off_diel, off_dlight, off_iso, off_solid, off_checker;
-    uint32_t off_tstack;  /* LDS offset of the per-lane traversal stacks: [MORT_OWN_STACK][thread] u16 */
+    uint32_t off_nodes4, off_leafrecs, off_leaves, off_lambert, off_metal, off_diel, off_dlight, off_iso, off_solid, off_checker;
+    uint32_t off_tstack;  /* LDS offset of the per-lane traversal stacks: [levels][thread] u16 (four-wide: the world's own bound, at most MORT_OWN4_STACK) */
     int node_first, node_count; /* the reference's threaded nodes in r.sc.nodes (HBM): fallback walk only */
     unsigned int *next_q; /* work counter, zeroed before launch */
     int tiles_x, tiles_total;
@@ -387,10 +390,10 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     if (threadIdx.x == 0) cam_view_fill(s_cam, s_fa.r);
     __syncthreads();
     const FastArgs &L = s_fa;
-    const DNode2 *nodes2 = (const DNode2 *)(lds + BU_U(L.off_nodes2));
+    const DNode4 *nodes4 = (const DNode4 *)(lds + BU_U(L.off_nodes4));
+    const DLeaf2 *leafrecs = (const DLeaf2 *)(lds + BU_U(L.off_leafrecs));
     const DBvhNode *leaves = (const DBvhNode *)(lds + BU_U(L.off_leaves));
     unsigned short *tstack = (unsigned short *)(lds + BU_U(L.off_tstack)) + threadIdx.x; /* [level * BLOCK] */
-    const DSphere *spheres = (const DSphere *)(lds + BU_U(L.off_spheres));
     const DLambert *lambert = (const DLambert *)(lds + BU_U(L.off_lambert));
     const DMetal *metal = (const DMetal *)(lds + BU_U(L.off_metal));
     const DDielectric *dielectric = (const DDielectric *)(lds + BU_U(L.off_diel));
@@ -417,7 +420,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     float ray_time0 = 0;
     OwnRay orr; orr.ix = orr.iy = orr.iz = 1; orr.mx = orr.my = orr.mz = 0; orr.band = 0; orr.invlen = 1;
     float ray_a = 1, closest = 0;
-    int best = -1;         /* sphere | leaf << 16 of the closest hit so far */
+    int best = -1;         /* closest hit so far: leaf << 16 | (second sphere of the leaf) << 15 */
     uint32_t node = 0;     /* T: own-tree node; L: leaf record */
     int sp = 0, flags = 0; /* pending far children; FL_TIE / FL_REF */
     V3 final_value = mk(0, 0, 0);
@@ -498,18 +501,30 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                 for (int rep = 0; rep < MORT_T_UNROLL; rep++) {
                 PROF(0, __popcll(__ballot(state == ST_T)));
                 if (state == ST_T) {
-                    const float4 *np = (const float4 *)(nodes2 + node);
-                    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                    float te0, te1;
-                    const bool m0 = own_prune(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q3.z, orr, closest, te0);
-                    const bool m1 = own_prune(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.w, orr, closest, te1);
-                    const uint32_t c0 = __float_as_uint(q3.x), c1 = __float_as_uint(q3.y);
-                    /* both hit: near child next, far child pushed; one hit: that child; none: pop, or done */
-                    const bool both = !m0 && !m1, none = m0 && m1;
-                    const bool first0 = te0 <= te1;
-                    uint32_t next = both ? (first0 ? c0 : c1) : (m0 ? c1 : c0);
-                    if (both) tstack[sp * BLOCK] = (unsigned short)(first0 ? c1 : c0);
-                    sp += both ? 1 : 0;
+                    /* four child boxes per step.  The children that pass are ordered by entry distance (the upper 16 bits of te, a
+                     * positive float, order as integers; the child reference rides in the lower 16): nearest next, the others
+                     * pushed farthest first.  The order only decides how soon `closest` shrinks -- equal distances are settled by
+                     * the reference's own walk (FL_TIE), never by the order of visits */
+                    const float4 *np = (const float4 *)(nodes4 + node);
+                    const float4 bx0 = np[0], bx1 = np[1], by0 = np[2], by1 = np[3], bz0 = np[4], bz1 = np[5], be = np[6];
+                    const uint4 ch = ((const uint4 *)np)[7];
+                    float t0, t1, t2, t3;
+                    const bool m0 = own_prune(bx0.x, bx1.x, by0.x, by1.x, bz0.x, bz1.x, be.x, orr, closest, t0);
+                    const bool m1 = own_prune(bx0.y, bx1.y, by0.y, by1.y, bz0.y, bz1.y, be.y, orr, closest, t1);
+                    const bool m2 = own_prune(bx0.z, bx1.z, by0.z, by1.z, bz0.z, bz1.z, be.z, orr, closest, t2) || ch.z == 0xffffu;
+                    const bool m3 = own_prune(bx0.w, bx1.w, by0.w, by1.w, bz0.w, bz1.w, be.w, orr, closest, t3) || ch.w == 0xffffu;
+                    uint32_t k0 = m0 ? 0xffffffffu : ((__float_as_uint(t0) & 0xffff0000u) | ch.x);
+                    uint32_t k1 = m1 ? 0xffffffffu : ((__float_as_uint(t1) & 0xffff0000u) | ch.y);
+                    uint32_t k2 = m2 ? 0xffffffffu : ((__float_as_uint(t2) & 0xffff0000u) | ch.z);
+                    uint32_t k3 = m3 ? 0xffffffffu : ((__float_as_uint(t3) & 0xffff0000u) | ch.w);
+#define MORT_CSWAP(a, b) do { const uint32_t lo_ = a < b ? a : b, hi_ = a < b ? b : a; a = lo_; b = hi_; } while (0)
+                    MORT_CSWAP(k0, k1); MORT_CSWAP(k2, k3); MORT_CSWAP(k0, k2); MORT_CSWAP(k1, k3); MORT_CSWAP(k1, k2);
+#undef MORT_CSWAP
+                    if (k3 != 0xffffffffu) { tstack[sp * BLOCK] = (unsigned short)k3; sp++; }
+                    if (k2 != 0xffffffffu) { tstack[sp * BLOCK] = (unsigned short)k2; sp++; }
+                    if (k1 != 0xffffffffu) { tstack[sp * BLOCK] = (unsigned short)k1; sp++; }
+                    uint32_t next = k0;
+                    const bool none = k0 == 0xffffffffu;
                     const bool have = !none || sp > 0;
                     if (none && sp > 0) { sp--; next = tstack[sp * BLOCK]; }
                     if (!have) { state = ST_S; kind = K_SHADE; }
@@ -529,17 +544,23 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
             /* ---- leaf: sphere::hit on the one or two spheres of a reference leaf node (objects.cuh:60-77,690-692) ---- */
             PROF(1, nL);
             if (state == ST_L) {
-                const uint32_t leaf_prims = leaves[node].prims;
-                const uint32_t pa = leaf_prims & 0x7fffu, pb = (leaf_prims >> 16) & 0x7fffu;
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const uint32_t p = k ? pb : pa;
-                    if (k == 1 && pb == pa) break;
-                    const DSphere sp_ = spheres[p];
-                    const float t = sphere_hit_root(sp_, ray, ray_a, 0.001f, closest);
-                    if (t != -1.0f) {
-                        if (t == closest && best >= 0) flags |= FL_TIE; /* the reference keeps whichever it visits last */
-                        closest = t; best = (int)(p | (node << 16));
+                /* both spheres by value in one round trip to LDS (DLeaf2) */
+                const float4 *lp = (const float4 *)(leafrecs + node);
+                const float4 a0 = lp[0], a1 = lp[1], b0 = lp[2], b1 = lp[3];
+                const uint32_t two = ((const uint4 *)lp)[4].z;
+                DSphere sa, sb;
+                sa.cx = a0.x; sa.cy = a0.y; sa.cz = a0.z; sa.radius = a0.w; sa.vx = a1.x; sa.vy = a1.y; sa.vz = a1.z; sa.mat = __float_as_uint(a1.w);
+                sb.cx = b0.x; sb.cy = b0.y; sb.cz = b0.z; sb.radius = b0.w; sb.vx = b1.x; sb.vy = b1.y; sb.vz = b1.z; sb.mat = __float_as_uint(b1.w);
+                const float ta = sphere_hit_root(sa, ray, ray_a, 0.001f, closest);
+                if (ta != -1.0f) {
+                    if (ta == closest && best >= 0) flags |= FL_TIE; /* the reference keeps whichever it visits last */
+                    closest = ta; best = (int)(node << 16);
+                }
+                if (two == 2u) {
+                    const float tb = sphere_hit_root(sb, ray, ray_a, 0.001f, closest);
+                    if (tb != -1.0f) {
+                        if (tb == closest && best >= 0) flags |= FL_TIE;
+                        closest = tb; best = (int)((node << 16) | 0x8000u);
                     }
                 }
                 if (sp > 0) {
@@ -565,17 +586,22 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                     if (!need_ref && best >= 0) need_ref = !slab_check(leaves[best >> 16], ray, orr, closest);
                     if (need_ref) { /* rare (about one segment in 10^5): the reference's own walk */
                         atomicAdd(&fap->r.counters[3], 1ull);
-                        const RefHit h = reference_walk(fap->r.sc.nodes, node_first, node_end, spheres, ray.o.x, ray.o.y, ray.o.z,
+                        const RefHit h = reference_walk(fap->r.sc.nodes, node_first, node_end, fap->r.sc.spheres, ray.o.x, ray.o.y, ray.o.z,
                                                         ray.d.x, ray.d.y, ray.d.z, ray.tm, ray_a);
-                        best = h.best; closest = h.closest;
+                        best = h.best; closest = h.closest; /* an index into the scene's sphere table (HBM) */
                     }
                 REGION("S:hitrecord");
-                    if (best >= 0) best &= 0x7fff;
                     if (best < 0) { /* camera.cuh:154-158 */
                         final_value = mk(bg_x, bg_y, bg_z);
                         kind = K_FINISH;
                     } else {
-                        const DSphere sp = spheres[best];
+                        DSphere sp;
+                        if (need_ref) sp = fap->r.sc.spheres[best];
+                        else { /* the winner's copy in its leaf record */
+                            const float4 *lp = (const float4 *)(leafrecs + (best >> 16)) + ((best & 0x8000) ? 2 : 0);
+                            const float4 s0 = lp[0], s1 = lp[1];
+                            sp.cx = s0.x; sp.cy = s0.y; sp.cz = s0.z; sp.radius = s0.w; sp.vx = s1.x; sp.vy = s1.y; sp.vz = s1.z; sp.mat = __float_as_uint(s1.w);
+                        }
                         const V3 p = ray_at(ray, closest);
                         const V3 outward = vdiv(vsub(p, sphere_center(sp, ray.tm)), sp.radius);
                         const bool front_face = vdot(ray.d, outward) < 0;

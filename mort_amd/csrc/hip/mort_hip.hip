@@ -213,7 +213,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     quiesce(c);
     mort_hip_comm_destroy(c);
     hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
-    hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
+    hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_trav); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_substates); hipFree(c->d_vaccum);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
     hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states); hipFree(c->d_deep); hipFree(c->d_wave_log);
@@ -247,6 +247,7 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
      * trees walked against the new scene tables */
     c->have_world = c->fast_ok = c->gen_ok = c->wave_ok = false;
     if (c->d_fast) { hipFree(c->d_fast); c->d_fast = nullptr; }
+    if (c->d_trav) { hipFree(c->d_trav); c->d_trav = nullptr; }
     if (c->d_gen) { hipFree(c->d_gen); c->d_gen = nullptr; }
     int st;
     SceneBlob sb;
@@ -265,19 +266,25 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     c->n_wspheres = (int)o.wspheres.size(); c->n_wquads = (int)o.wquads.size(); c->n_lists = w->objs.num_hittable_list;
     /* the LDS kernels handle: one BVH over spheres as the whole world */
     c->wave_ok = (o.items.size() == 1 && o.items[0].kind == ITEM_BVH && o.quads.empty());
-    if (c->wave_ok && !o.own_nodes.empty()) {
-        std::vector<unsigned char> fb;
-        c->f_nodes2 = (uint32_t)place(fb, o.own_nodes); c->f_leaves = (uint32_t)place(fb, o.own_leaves);
-        c->f_spheres = (uint32_t)place(fb, o.spheres);
+    if (c->wave_ok && !o.own_nodes.empty() && !o.own_nodes4.empty()) {
+        /* two LDS images: the BVH megakernel's (four-wide nodes, leaf records with their spheres by value, leaf boxes, every small
+         * table) and the wavefront traversal kernel's (binary nodes, leaf nodes, spheres) */
+        std::vector<unsigned char> fb, tb;
+        c->f_nodes4 = (uint32_t)place(fb, o.own_nodes4); c->f_leafrecs = (uint32_t)place(fb, o.own_leafrecs);
+        c->f_leaves = (uint32_t)place(fb, o.own_leaves);
         c->f_lambert = (uint32_t)place(fb, o.lambert); c->f_metal = (uint32_t)place(fb, o.metal); c->f_diel = (uint32_t)place(fb, o.dielectric);
         c->f_dlight = (uint32_t)place(fb, o.dlight); c->f_iso = (uint32_t)place(fb, o.isotropic);
         c->f_solid = (uint32_t)place(fb, o.solid); c->f_checker = (uint32_t)place(fb, o.checker);
         fb.resize((fb.size() + 15) & ~(size_t)15, 0);
-        if (fb.size() <= 72 * 1024) {
+        c->t_nodes2 = (uint32_t)place(tb, o.own_nodes); c->t_leaves = (uint32_t)place(tb, o.own_leaves); c->t_spheres = (uint32_t)place(tb, o.spheres);
+        tb.resize((tb.size() + 15) & ~(size_t)15, 0);
+        if (fb.size() <= 72 * 1024 && tb.size() <= 72 * 1024) {
             HIPCHK(c, hipMalloc(&c->d_fast, fb.size()));
             HIPCHK(c, hipMemcpy(c->d_fast, fb.data(), fb.size(), hipMemcpyHostToDevice));
-            c->fast_bytes = (uint32_t)fb.size();
-            c->own_nodes = (int)o.own_nodes.size(); c->own_leaves = (int)o.own_leaves.size();
+            HIPCHK(c, hipMalloc(&c->d_trav, tb.size()));
+            HIPCHK(c, hipMemcpy(c->d_trav, tb.data(), tb.size(), hipMemcpyHostToDevice));
+            c->fast_bytes = (uint32_t)fb.size(); c->trav_bytes = (uint32_t)tb.size();
+            c->own_nodes = (int)o.own_nodes.size(); c->own_leaves = (int)o.own_leaves.size(); c->own4_stack = o.own4_stack > 1 ? o.own4_stack : 1;
             c->fast_ok = true;
         }
     }
@@ -450,10 +457,10 @@ static int render_wavefront(mort_ctx *c, const RenderArgs &a, const mort_camera 
     HIPCHK(c, hipGetLastError());
     auto trav = wf_trav<MORT_WF_BLOCK>;
     const size_t stage_bytes = (size_t)(MORT_WF_BLOCK / 64) * 3 * MORT_WF_STAGE * sizeof(unsigned);
-    /* wf_trav's LDS: the megakernel's image (own tree, leaf records, spheres, ...) | traversal stacks | class staging | prefetch rings */
-    w.trav_src = (const unsigned char *)c->d_fast; w.trav_bytes = c->fast_bytes;
-    w.t_nodes2 = c->f_nodes2; w.t_leaves = c->f_leaves; w.t_spheres = c->f_spheres;
-    w.t_tstack = (c->fast_bytes + 15u) & ~15u;
+    /* wf_trav's LDS: its image (binary own tree, leaf nodes, spheres) | traversal stacks | class staging | prefetch rings */
+    w.trav_src = (const unsigned char *)c->d_trav; w.trav_bytes = c->trav_bytes;
+    w.t_nodes2 = c->t_nodes2; w.t_leaves = c->t_leaves; w.t_spheres = c->t_spheres;
+    w.t_tstack = (c->trav_bytes + 15u) & ~15u;
     w.t_stage = w.t_tstack + (uint32_t)MORT_OWN_STACK * (uint32_t)MORT_WF_BLOCK * 2u;
     const size_t ring_off = (((size_t)w.t_stage + stage_bytes) + 1023) & ~(size_t)1023;
     const size_t trav_lds = ring_off + (size_t)(MORT_WF_BLOCK / 64) * 4096;
@@ -690,14 +697,14 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
     } else if (blocks > 0 && mode == MORT_MODE_WAVE) {
         int st_w = render_wavefront(c, a, cam, s);
         if (st_w != MORT_OK) return st_w;
-        lds_bytes_used = (int)c->fast_bytes;
+        lds_bytes_used = (int)c->trav_bytes;
         std::snprintf(kname, sizeof kname, "wf_trav<%d>", MORT_WF_BLOCK);
     } else if (blocks > 0 && use_fast) {
         FastArgs fa;
         std::memset(&fa, 0, sizeof fa);
         fa.r = a;
         fa.hot_src = (const unsigned char *)c->d_fast; fa.hot_bytes = c->fast_bytes;
-        fa.off_nodes2 = c->f_nodes2; fa.off_leaves = c->f_leaves; fa.off_spheres = c->f_spheres; fa.off_lambert = c->f_lambert; fa.off_metal = c->f_metal;
+        fa.off_nodes4 = c->f_nodes4; fa.off_leaves = c->f_leaves; fa.off_leafrecs = c->f_leafrecs; fa.off_lambert = c->f_lambert; fa.off_metal = c->f_metal;
         fa.off_diel = c->f_diel; fa.off_dlight = c->f_dlight; fa.off_iso = c->f_iso; fa.off_solid = c->f_solid; fa.off_checker = c->f_checker;
         fa.node_first = 0; fa.node_count = c->sc.n_nodes; /* the reference's threaded nodes (HBM): fallback walk */
         fa.next_q = (unsigned int *)(c->d_counters + 2);
@@ -741,8 +748,8 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             if (th) { int s_ = 0, l_ = 0, k_ = 0; if (std::sscanf(th, "%d,%d,%d", &s_, &l_, &k_) == 3) { fa.th_s = s_; fa.th_l = l_; fa.t_keep = k_; } }
         }
         /* LDS: hot blob + as many bounce-stack levels per lane as fit next to it (768 threads: one workgroup per CU) */
-        const uint32_t tstack_off = (c->fast_bytes + 15u) & ~15u; /* traversal stacks: [MORT_OWN_STACK][thread] u16 */
-        const uint32_t stack_off = tstack_off + (uint32_t)MORT_OWN_STACK * (uint32_t)FB * 2u;
+        const uint32_t tstack_off = (fa.hot_bytes + 15u) & ~15u; /* traversal stacks: [levels][thread] u16 (four-wide: the world's own bound, at most MORT_OWN4_STACK) */
+        const uint32_t stack_off = tstack_off + (uint32_t)c->own4_stack * (uint32_t)FB * 2u; /* as many levels as this world's tree can have pending */
         fa.off_tstack = tstack_off;
         uint32_t static_lds = 1024; /* the kernel's own __shared__ objects come out of the same 160 KB */
         { hipFuncAttributes fattr; if (hipFuncGetAttributes(&fattr, (const void *)kern) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 1023) & ~(size_t)1023); }
@@ -992,6 +999,59 @@ extern "C" int mort_hip_debug_wave_log(mort_ctx *c, unsigned long long *out, siz
     const size_t n = c->wave_log_waves < max_waves ? c->wave_log_waves : max_waves;
     if (hipMemcpy(out, c->d_wave_log, n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return (int)n;
+}
+
+/* diagnostic (not in include/mort_hip.h; host only, no HIP call): facts of this build's own trees over a world -- out[0] binary
+ * nodes, [1] leaves, [2] binary depth, [3] four-wide nodes, [4] its pending-children bound, [5] leaf references reached from the
+ * four-wide root, [6] leaves reached more than once or out of range, [7] child slots in use, [8] 1 if every four-wide box and margin
+ * is bit for bit one of the binary tree's for the same child. */
+extern "C" int mort_hip_debug_own_tree(const mort_world *w, int *out) {
+    if (!w || !out) return MORT_ERR_INVALID;
+    SceneBlob sb;
+    const int st = build_scene_blob(w, sb);
+    if (st != MORT_OK) return st;
+    const mortc::Compiled &o = sb.comp;
+    for (int i = 0; i < 9; i++) out[i] = 0;
+    out[0] = (int)o.own_nodes.size(); out[1] = (int)o.own_leaves.size(); out[2] = o.own_depth;
+    out[3] = (int)o.own_nodes4.size(); out[4] = o.own4_stack;
+    if (o.own_nodes4.empty()) return MORT_OK;
+    /* child reference -> (box, margin) in the binary tree */
+    struct Rec { float v[7]; };
+    std::vector<Rec> of_inner(o.own_nodes.size()), of_leaf(o.own_leaves.size());
+    for (const DNode2 &nd : o.own_nodes)
+        for (int k = 0; k < 2; k++) {
+            const uint32_t ref = k ? nd.child1 : nd.child0;
+            Rec r = k ? Rec{{nd.x1min, nd.x1max, nd.y1min, nd.y1max, nd.z1min, nd.z1max, nd.e1}} : Rec{{nd.x0min, nd.x0max, nd.y0min, nd.y0max, nd.z0min, nd.z0max, nd.e0}};
+            if (ref & 0x8000u) of_leaf[ref & 0x7fffu] = r; else of_inner[ref] = r;
+        }
+    std::vector<int> seen(o.own_leaves.size(), 0);
+    std::vector<uint32_t> todo(1, 0u);
+    bool same = true;
+    /* every inner child of a four-wide node stands for one binary node: find which by its box, via the leaves below it */
+    while (!todo.empty()) {
+        const uint32_t n = todo.back(); todo.pop_back();
+        const DNode4 &nd = o.own_nodes4[n];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t ref = nd.child[k];
+            if (ref == 0xffffu) continue;
+            out[7]++;
+            const Rec r{{nd.xmin[k], nd.xmax[k], nd.ymin[k], nd.ymax[k], nd.zmin[k], nd.zmax[k], nd.e[k]}};
+            if (ref & 0x8000u) {
+                const uint32_t l = ref & 0x7fffu;
+                if (l >= seen.size() || seen[l]++) { out[6]++; continue; }
+                out[5]++;
+                if (std::memcmp(&r, &of_leaf[l], sizeof r) != 0) same = false;
+            } else {
+                if (ref >= o.own_nodes4.size()) { out[6]++; continue; }
+                bool found = false;
+                for (const Rec &b : of_inner) if (std::memcmp(&r, &b, sizeof r) == 0) { found = true; break; }
+                if (!found) same = false;
+                todo.push_back(ref);
+            }
+        }
+    }
+    out[8] = same ? 1 : 0;
+    return MORT_OK;
 }
 
 extern "C" int mort_hip_render_device(mort_ctx *c, const mort_camera *cam, int mode, void *d_rgba, void *d_accum,

@@ -46,6 +46,9 @@ struct Compiled {
     std::vector<DNode2> own_nodes;
     std::vector<DBvhNode> own_leaves;
     int own_depth = 0;
+    std::vector<DLeaf2> own_leafrecs; /* own_leaves[i]'s spheres by value */
+    std::vector<DNode4> own_nodes4; /* own_nodes, four children wide (collapse_own_tree); empty when its pending-children bound does not hold */
+    int own4_stack = 0;             /* most children a walk of own_nodes4 can have pending */
     /* this build's UNIFIED tree over every solid primitive of a world without reference BVHs (mega_gen.hip):
      * see build_unified() */
     bool g_ok = false;
@@ -300,7 +303,7 @@ struct Compiler {
         return (uint32_t)me;
     }
     void build_own_tree() {
-        out.own_nodes.clear(); out.own_leaves.clear(); out.own_depth = 0;
+        out.own_nodes.clear(); out.own_leaves.clear(); out.own_depth = 0; out.own_nodes4.clear(); out.own4_stack = 0; out.own_leafrecs.clear();
         if (out.items.size() != 1 || out.items[0].kind != ITEM_BVH || !out.quads.empty()) return;
         const DItem &it = out.items[0];
         OwnBuild ob;
@@ -326,6 +329,68 @@ struct Compiler {
         for (const DNode2 &nd : out.own_nodes) if (!std::isfinite(nd.e0) || !std::isfinite(nd.e1)) { out.own_nodes.clear(); return; }
         out.own_leaves = leaves;
         out.own_depth = ob.max_depth_seen + 1;
+        for (const DBvhNode &lf : leaves) {
+            DLeaf2 r;
+            std::memset(&r, 0, sizeof r);
+            r.pa = lf.prims & 0x7fffu; r.pb = (lf.prims >> 16) & 0x7fffu; r.n = r.pa == r.pb ? 1u : 2u;
+            if (r.pa >= out.spheres.size() || r.pb >= out.spheres.size()) { out.own_nodes.clear(); out.own_leaves.clear(); return; }
+            r.a = out.spheres[r.pa]; r.b = out.spheres[r.pb];
+            out.own_leafrecs.push_back(r);
+        }
+        collapse_own_tree();
+    }
+    /* ---- own_nodes four children wide.  Starting from a binary node's two children, the inner child with the largest box is replaced
+     * by its own two children until four slots are taken (or only leaves are left).  Slot order is irrelevant to the result: the walk
+     * orders the children it enters by entry distance, and equal hit distances are referred to the reference's walk whatever the order
+     * (mega_bvh.h).  Returns the most children a walk below this node can have pending: a step leaves at most (slots - 1) behind. ---- */
+    int collapse_emit(uint32_t b2, uint32_t me) {
+        struct Slot { uint32_t ref; float lo[3], hi[3], e; };
+        auto slot_of = [](const DNode2 &nd, int k) {
+            Slot s;
+            s.ref = k ? nd.child1 : nd.child0; s.e = k ? nd.e1 : nd.e0;
+            s.lo[0] = k ? nd.x1min : nd.x0min; s.hi[0] = k ? nd.x1max : nd.x0max;
+            s.lo[1] = k ? nd.y1min : nd.y0min; s.hi[1] = k ? nd.y1max : nd.y0max;
+            s.lo[2] = k ? nd.z1min : nd.z0min; s.hi[2] = k ? nd.z1max : nd.z0max;
+            return s;
+        };
+        std::vector<Slot> sl;
+        sl.push_back(slot_of(out.own_nodes[b2], 0)); sl.push_back(slot_of(out.own_nodes[b2], 1));
+        while (sl.size() < 4) {
+            int pick = -1; double pa = -1;
+            for (size_t i = 0; i < sl.size(); i++) {
+                if (sl[i].ref & 0x8000u) continue;
+                Box b; for (int k = 0; k < 3; k++) { b.lo[k] = sl[i].lo[k]; b.hi[k] = sl[i].hi[k]; }
+                const double a = box_area(b);
+                if (a > pa) { pa = a; pick = (int)i; }
+            }
+            if (pick < 0) break;
+            const DNode2 &nd = out.own_nodes[sl[pick].ref];
+            sl[pick] = slot_of(nd, 0);
+            sl.insert(sl.begin() + pick + 1, slot_of(nd, 1));
+        }
+        int below = 0;
+        DNode4 n4;
+        std::memset(&n4, 0, sizeof n4);
+        for (int k = 0; k < 4; k++) n4.child[k] = 0xffffu;
+        for (size_t i = 0; i < sl.size(); i++) {
+            n4.xmin[i] = sl[i].lo[0]; n4.xmax[i] = sl[i].hi[0]; n4.ymin[i] = sl[i].lo[1]; n4.ymax[i] = sl[i].hi[1];
+            n4.zmin[i] = sl[i].lo[2]; n4.zmax[i] = sl[i].hi[2]; n4.e[i] = sl[i].e;
+            if (sl[i].ref & 0x8000u) { n4.child[i] = sl[i].ref; continue; }
+            const uint32_t ci = (uint32_t)out.own_nodes4.size();
+            out.own_nodes4.push_back(DNode4{});
+            n4.child[i] = ci;
+            const int d = collapse_emit(sl[i].ref, ci);
+            if (d > below) below = d;
+        }
+        out.own_nodes4[me] = n4;
+        return (int)sl.size() - 1 + below;
+    }
+    void collapse_own_tree() {
+        out.own_nodes4.clear(); out.own4_stack = 0;
+        if (out.own_nodes.empty()) return;
+        out.own_nodes4.push_back(DNode4{});
+        out.own4_stack = collapse_emit(0, 0);
+        if (out.own4_stack > MORT_OWN4_STACK || out.own_nodes4.size() > 0x7fff) out.own_nodes4.clear();
     }
 
     /* ---- this build's UNIFIED tree (mega_gen.hip, wave_gen.hip).  A world without reference BVHs is a linear

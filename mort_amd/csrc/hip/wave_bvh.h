@@ -42,7 +42,7 @@
 struct WfArgs {
     RenderArgs r;
     uint32_t off_ring;        /* LDS offset of the per-wave prefetch rings (wf_trav) */
-    /* wf_trav's own LDS image: the BVH megakernel's (own tree, reference leaf records, spheres, ...) */
+    /* wf_trav's own LDS image (binary own tree, reference leaf nodes, spheres) */
     const unsigned char *trav_src; uint32_t trav_bytes;
     uint32_t t_nodes2, t_leaves, t_spheres, t_tstack, t_stage;
     int node_first, node_count;

@@ -52,3 +52,56 @@ def test_no_gpu_means_no_render_path():
     with pytest.raises(hip.MortHipError) as e:
         hip.Context(0)
     assert e.value.status == -2  # MORT_ERR_NO_DEVICE
+
+
+def test_state_machine_kernels_have_no_private_memory():
+    """The code objects inside the built library (llvm-objdump --offloading + llvm-readelf --notes): every kernel's register allocation can
+    host the workgroup its launch bounds promise, and mega_bvh_kernel / mega_gen_kernel neither spill a vector register nor touch private
+    memory beyond a callee frame (round 2's 1 984 B per lane are gone, and must stay gone).  Needs the ROCm LLVM tools, no GPU."""
+    import shutil
+    import subprocess
+    import sys
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or not shutil.which("c++filt"):
+        pytest.skip("ROCm LLVM tools not installed")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "kernel_resources.py"), hip.LIB_PATH, "--check"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    rows = {l.split()[0] + " " + " ".join(l.split()[1:-7]): l.split()[-7:] for l in p.stdout.splitlines() if l.startswith("mega_")}
+    gen = [v for k, v in rows.items() if k.startswith("mega_gen_kernel<768") or k.startswith("mega_gen_kernel<512")]
+    assert gen and all(v[3] == "0" and v[5] == "0" for v in gen), rows  # no spilled VGPR, 0 B of private memory
+
+
+@pytest.mark.gpu
+def test_roofline_calibration_kernels(gpu_ctx):
+    """mort_hip_calib_valu / mort_hip_calib_hbm_copy (bench.py's roofline calibration): a SIMD cannot issue a wave64 VALU instruction faster than
+    the SIMD-32's two cycles, a lone wave is slower than a full SIMD, fp64 is slower than fp32, and the copy moves at a plausible HBM rate."""
+    one = gpu_ctx.calib_valu(1, 0)
+    four = gpu_ctx.calib_valu(4, 0)
+    f64 = gpu_ctx.calib_valu(4, 2)
+    assert one["simds_seen"] == four["simds_seen"] == 1024 and four["resident_waves_per_simd"] == 4
+    assert 1.9 < four["cycles_per_valu_per_simd"] < 3.0 < one["cycles_per_valu_per_simd"] < 6.0
+    assert f64["cycles_per_valu_per_simd"] > 1.5 * four["cycles_per_valu_per_simd"]
+    assert 1.0 < one["clock_ghz"] < 2.6
+    assert 2000 < gpu_ctx.calib_hbm_copy(1 << 29, 2) < 8000
+
+
+@pytest.mark.parametrize("sid", [1, 10])
+def test_four_wide_tree_is_the_binary_tree_regrouped(sid):
+    """The BVH megakernel's four-wide nodes (scene_compile.h collapse_own_tree) are this build's binary tree over the reference's
+    leaf nodes with inner nodes opened in place: every leaf is reached exactly once, every box and margin is one of the binary
+    tree's bit for bit, and the pending-children bound the kernel's LDS stack is sized for holds (host only, no GPU)."""
+    import ctypes as C
+    from mort_amd import hip, host
+    world, _ = host.build_scene(sid, width=64, spp=1)
+    fn = hip.lib().mort_hip_debug_own_tree
+    fn.restype = C.c_int
+    out = (C.c_int * 9)()
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    assert fn(C.cast(world.ptr, C.c_void_p), out) == 0
+    n2, leaves, depth2, n4, stack4, reached, bad, slots, same = list(out)
+    assert n2 == leaves - 1 and leaves >= 19 and depth2 <= 15
+    assert 0 < n4 <= n2 // 2                    # three binary nodes fold into one in the best case
+    assert reached == leaves and bad == 0
+    assert slots == n4 - 1 + leaves              # every node but the root and every leaf is somebody's child
+    assert slots >= 2.9 * n4                     # three of four slots in use on average (the lowest nodes hold two or three leaves)
+    assert 3 <= stack4 <= 24
+    assert same == 1
