@@ -61,8 +61,8 @@ struct __attribute__((aligned(16))) DNode2 {
 };
 /* The same tree four children wide (scene_compile.h collapse_own_tree; the BVH megakernel's box step): 128 B = eight ds_read_b128,
  * child k's planes at [k] of each array.  A binary node's larger inner child is opened in place until four slots are full, so
- * one step tests what two to three binary steps did and the loads of a step are all independent.  Child references as in
- * DNode2; an unused slot is 0xffff (never entered).  Boxes and margins are the binary tree's, bit for bit. */
+ * one step tests what two to three binary steps did and the loads of a step are all independent.  Child references are
+ * pre-scaled (below); an unused slot is 0xffff (never entered).  Boxes and margins are the binary tree's, bit for bit. */
 struct __attribute__((aligned(16))) DNode4 {
     float xmin[4], xmax[4], ymin[4], ymax[4], zmin[4], zmax[4], e[4];
     uint32_t child[4];
@@ -70,14 +70,19 @@ struct __attribute__((aligned(16))) DNode4 {
                       * 64 banks.  With a stride of 128 B those pieces lie on two bank positions (8-way conflicts, measured: 45 % of the kernel's LDS cycles);
                       * an odd number of pieces per node spreads them over all sixteen */
 };
-/* What the leaf step of the BVH megakernel reads, in ONE round trip to LDS: the one or two spheres of a reference leaf node by value.
- * 80 B = 5 x 16, an odd number of pieces again.  (The leaf node's box, for the final check of the winner, stays in the DBvhNode array.) */
+/* What the leaf step of the BVH megakernel reads, in ONE round trip to LDS: the one or two spheres of a reference leaf node by value;
+ * then the leaf node's own box, bit for bit, for the final check of the winner.  112 B = 7 x 16, an odd number of pieces again.
+ * References to both kinds of record are pre-scaled to 16-byte pieces so that an address is one shift-add: an inner child is
+ * MORT_NODE4_PIECES x its node index, a leaf child 0x8000 | MORT_LEAF2_PIECES x its leaf index. */
 struct __attribute__((aligned(16))) DLeaf2 {
     DSphere a, b;     /* b == a when the leaf holds one sphere */
-    uint32_t pa, pb;  /* their indices in the scene's sphere table */
+    float xmin, xmax, ymin, ymax, zmin, zmax;
     uint32_t n;       /* 1 or 2 */
-    uint32_t pad;
+    uint32_t prims;   /* pa | pb << 16: their indices in the scene's sphere table */
+    uint32_t pad[4];
 };
+#define MORT_NODE4_PIECES 9
+#define MORT_LEAF2_PIECES 7
 #define MORT_OWN4_STACK 24 /* pending children per lane of the four-wide walk: a step pushes at most 3; the builder checks the worst path */
 /* Node of the UNIFIED tree (scene_compile.h build_unified): 32 B = two ds_read_b128.  The boxes of its two children as 8-bit offsets
  * from the node's own corner, in steps of a power of two per axis: plane = fmaf((float)q, step, origin).  The builder rounds every

@@ -53,7 +53,7 @@ struct FastArgs {
     RenderArgs r;
     const unsigned char *hot_src; /* device copy of the kernel's LDS image */
     uint32_t hot_bytes;
-    uint32_t off_nodes4, off_leafrecs, off_leaves, off_lambert, off_metal, off_diel, off_dlight, off_iso, off_solid, off_checker;
+    uint32_t off_nodes4, off_leafrecs, off_lambert, off_metal, off_diel, off_dlight, off_iso, off_solid, off_checker;
     uint32_t off_tstack;  /* LDS offset of the per-lane traversal stacks: [levels][thread] u16 (four-wide: the world's own bound, at most MORT_OWN4_STACK) */
     int node_first, node_count; /* the reference's threaded nodes in r.sc.nodes (HBM): fallback walk only */
     unsigned int *next_q; /* work counter, zeroed before launch */
@@ -221,7 +221,7 @@ enum { K_SHADE = 0, K_FINISH = 1, K_NEWSAMPLE = 2, K_NEWPIX = 3 };
 #define MORT_TH_L 16
 #endif
 #ifndef MORT_T_UNROLL
-#define MORT_T_UNROLL 2 /* box steps per check of the lane count */
+#define MORT_T_UNROLL 1 /* box steps per check of the lane count (four-wide steps: 1 measured 111.6 ms, 2 113.0, 3 116.6 on Scene 1) */
 #endif
 #ifndef MORT_T_KEEP
 #define MORT_T_KEEP 16
@@ -362,7 +362,7 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
  * (A thin wrapper kernel around a shared body would keep the three-parameter symbol names, but it perturbs the frame kernel's register
  * allocation: 136 instead of 122 scratch instructions) */
 template <int BLOCK, bool PROBE, bool DRAIN = false, bool SUB = false>
-__global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) / 256 : MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs MORT_BVH_ARG_NAME) {
+__global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (DRAIN && BLOCK < 768) ? (BLOCK + 255) / 256 : MORT_MIN_WAVES) mega_bvh_kernel(const FastArgs MORT_BVH_ARG_NAME) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     /* The by-value parameter is never named: round 2's kernel took its address for the out-of-line helpers, so hipcc kept a private
      * copy of the argument struct per lane (592 B of scratch) and read wave-uniform fields from it inside the state loop.  The kernarg
@@ -390,10 +390,13 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     if (threadIdx.x == 0) cam_view_fill(s_cam, s_fa.r);
     __syncthreads();
     const FastArgs &L = s_fa;
-    const DNode4 *nodes4 = (const DNode4 *)(lds + BU_U(L.off_nodes4));
-    const DLeaf2 *leafrecs = (const DLeaf2 *)(lds + BU_U(L.off_leafrecs));
-    const DBvhNode *leaves = (const DBvhNode *)(lds + BU_U(L.off_leaves));
-    unsigned short *tstack = (unsigned short *)(lds + BU_U(L.off_tstack)) + threadIdx.x; /* [level * BLOCK] */
+    /* both record arrays as 16-byte pieces: a child reference is already a piece index (dev_scene.h) */
+    static_assert(sizeof(DNode4) == 16 * MORT_NODE4_PIECES && sizeof(DLeaf2) == 16 * MORT_LEAF2_PIECES, "record strides");
+    const float4 *nodes4 = (const float4 *)(lds + BU_U(L.off_nodes4));
+    const float4 *leafrecs = (const float4 *)(lds + BU_U(L.off_leafrecs));
+    /* traversal stack [level][thread] u16, addressed by the LDS byte offset of the lane's next free entry */
+    const uint32_t ts_base = BU_U(L.off_tstack) + 2u * threadIdx.x;
+#define TS_AT(off) (*(unsigned short *)(lds + (off)))
     const DLambert *lambert = (const DLambert *)(lds + BU_U(L.off_lambert));
     const DMetal *metal = (const DMetal *)(lds + BU_U(L.off_metal));
     const DDielectric *dielectric = (const DDielectric *)(lds + BU_U(L.off_diel));
@@ -422,8 +425,8 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     float ray_a = 1, closest = 0;
     int best = -1;         /* closest hit so far: leaf << 16 | (second sphere of the leaf) << 15 */
     uint32_t node = 0;     /* T: own-tree node; L: leaf record */
-    int sp = 0, flags = 0; /* pending far children; FL_TIE / FL_REF */
-    V3 final_value = mk(0, 0, 0);
+    uint32_t spa = ts_base; /* pending children: next free entry of the lane's traversal stack */
+    int flags = 0;          /* FL_TIE / FL_REF */
     /* bounce-stack levels below the LDS part: [level - DL][lane of the launch] in HBM, one coalesced 1 KB row per wave and level, touched
      * only by paths deeper than the LDS part (a private array is scratch memory sized for the deepest path in every lane) */
     float4 *stack_deep = BU_P(L.deep) + ((size_t)blockIdx.x * BLOCK + threadIdx.x);
@@ -445,12 +448,20 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     const unsigned long long prof_r0 = __builtin_amdgcn_s_memrealtime();
 #define PROF(i, lanes) do { prof[2 * (i)] += 1; prof[2 * (i) + 1] += (unsigned long long)(lanes); } while (0)
     unsigned long long profb[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* S branches: steps entered, lanes: metal, dielectric, lambertian, finish, get_ray, unwind iterations */
+#ifdef MORT_PROFILE_FINE /* cycles of the parts of the shade step instead of the branch counts (whose atomics distort the step's time) */
+#define PROFB(i) do { } while (0)
+    unsigned long long proff[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; /* verify, hit record, metal, dielectric, lambert texture, lambert scatter, light, stack store */
+#define PROFF(i) do { ps1 = __builtin_readcyclecounter(); proff[i] += ps1 - ps0; profc[4] += ps1 - ps0; ps0 = ps1; } while (0)
+#else
+#define PROFF(i) do { } while (0)
 #define PROFB(i) do { const unsigned long long m_ = __ballot(1); if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) { \
         atomicAdd(&counters_p[18 + 2 * (i)], 1ull); atomicAdd(&counters_p[19 + 2 * (i)], (unsigned long long)__popcll(m_)); } } while (0)
+#endif
 #define PROFC(i) do { pt1 = __builtin_readcyclecounter(); profc[i] += pt1 - pt0; pt0 = pt1; } while (0)
 #else
 #define PROF(i, lanes) do { } while (0)
 #define PROFB(i) do { } while (0)
+#define PROFF(i) do { } while (0)
 #define PROFC(i) do { } while (0)
 #define PROFS0() do { } while (0)
 #define PROFS(i) do { } while (0)
@@ -463,7 +474,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     int leader = -1;
     const bool drain_rounds = DRAIN && BU_I(L.drain_rounds) == 1;
     const bool live_thresholds = BU_I(L.drain_rounds) == 3;
-    /* Loop shape: the scheduler and the two traversal states form an INNER loop in which only (state, node, sp, kind, closest, best, flags)
+    /* Loop shape: the scheduler and the two traversal states form an INNER loop in which only (state, node, spa, kind, closest, best, flags)
      * change; the shade step, which rewrites the whole per-lane state, is the outer loop's body.  As one flat loop hipcc gave every step
      * -- box steps included -- a round trip of some fifty register copies at the common join of the three branches */
     bool running = true;
@@ -505,7 +516,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                      * positive float, order as integers; the child reference rides in the lower 16): nearest next, the others
                      * pushed farthest first.  The order only decides how soon `closest` shrinks -- equal distances are settled by
                      * the reference's own walk (FL_TIE), never by the order of visits */
-                    const float4 *np = (const float4 *)(nodes4 + node);
+                    const float4 *np = nodes4 + node;
                     const float4 bx0 = np[0], bx1 = np[1], by0 = np[2], by1 = np[3], bz0 = np[4], bz1 = np[5], be = np[6];
                     const uint4 ch = ((const uint4 *)np)[7];
                     float t0, t1, t2, t3;
@@ -520,13 +531,13 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
 #define MORT_CSWAP(a, b) do { const uint32_t lo_ = a < b ? a : b, hi_ = a < b ? b : a; a = lo_; b = hi_; } while (0)
                     MORT_CSWAP(k0, k1); MORT_CSWAP(k2, k3); MORT_CSWAP(k0, k2); MORT_CSWAP(k1, k3); MORT_CSWAP(k1, k2);
 #undef MORT_CSWAP
-                    if (k3 != 0xffffffffu) { tstack[sp * BLOCK] = (unsigned short)k3; sp++; }
-                    if (k2 != 0xffffffffu) { tstack[sp * BLOCK] = (unsigned short)k2; sp++; }
-                    if (k1 != 0xffffffffu) { tstack[sp * BLOCK] = (unsigned short)k1; sp++; }
+                    if (k3 != 0xffffffffu) { TS_AT(spa) = (unsigned short)k3; spa += 2u * BLOCK; }
+                    if (k2 != 0xffffffffu) { TS_AT(spa) = (unsigned short)k2; spa += 2u * BLOCK; }
+                    if (k1 != 0xffffffffu) { TS_AT(spa) = (unsigned short)k1; spa += 2u * BLOCK; }
                     uint32_t next = k0;
                     const bool none = k0 == 0xffffffffu;
-                    const bool have = !none || sp > 0;
-                    if (none && sp > 0) { sp--; next = tstack[sp * BLOCK]; }
+                    const bool have = !none || spa != ts_base;
+                    if (none && spa != ts_base) { spa -= 2u * BLOCK; next = TS_AT(spa); }
                     if (!have) { state = ST_S; kind = K_SHADE; }
                     else { node = next & 0x7fffu; if (next & 0x8000u) state = ST_L; }
                 }
@@ -545,9 +556,9 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
             PROF(1, nL);
             if (state == ST_L) {
                 /* both spheres by value in one round trip to LDS (DLeaf2) */
-                const float4 *lp = (const float4 *)(leafrecs + node);
+                const float4 *lp = leafrecs + node;
                 const float4 a0 = lp[0], a1 = lp[1], b0 = lp[2], b1 = lp[3];
-                const uint32_t two = ((const uint4 *)lp)[4].z;
+                const uint32_t two = ((const uint4 *)lp)[5].z;
                 DSphere sa, sb;
                 sa.cx = a0.x; sa.cy = a0.y; sa.cz = a0.z; sa.radius = a0.w; sa.vx = a1.x; sa.vy = a1.y; sa.vz = a1.z; sa.mat = __float_as_uint(a1.w);
                 sb.cx = b0.x; sb.cy = b0.y; sb.cz = b0.z; sb.radius = b0.w; sb.vx = b1.x; sb.vy = b1.y; sb.vz = b1.z; sb.mat = __float_as_uint(b1.w);
@@ -563,9 +574,9 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                         closest = tb; best = (int)((node << 16) | 0x8000u);
                     }
                 }
-                if (sp > 0) {
-                    sp--;
-                    const uint32_t next = tstack[sp * BLOCK];
+                if (spa != ts_base) {
+                    spa -= 2u * BLOCK;
+                    const uint32_t next = TS_AT(spa);
                     node = next & 0x7fffu;
                     state = (next & 0x8000u) ? ST_L : ST_T;
                 } else { state = ST_S; kind = K_SHADE; }
@@ -578,18 +589,28 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
             /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
             PROF(2, nS);
             PROFS0();
+            /* a path's result lives inside one shade step: set where the path ends, consumed by the finish part below.  (The two
+             * degenerate launches -- no samples, no bounces -- enter a step with K_FINISH and a value of zero.) */
+            V3 final_value = mk(0, 0, 0);
                 REGION("S:verify");
             if (state == ST_S) {
                 if (kind == K_SHADE) {
                     /* is the winner what bvh_node::hit returns?  (header comment) */
                     bool need_ref = flags != 0;
-                    if (!need_ref && best >= 0) need_ref = !slab_check(leaves[best >> 16], ray, orr, closest);
+                    if (!need_ref && best >= 0) { /* the winner's leaf box, from its record */
+                        const float4 *lp = leafrecs + (best >> 16);
+                        const float4 b0 = lp[4], b1 = lp[5];
+                        DBvhNode lb;
+                        lb.xmin = b0.x; lb.xmax = b0.y; lb.ymin = b0.z; lb.ymax = b0.w; lb.zmin = b1.x; lb.zmax = b1.y; lb.skip = 0; lb.prims = 0;
+                        need_ref = !slab_check(lb, ray, orr, closest);
+                    }
                     if (need_ref) { /* rare (about one segment in 10^5): the reference's own walk */
                         atomicAdd(&fap->r.counters[3], 1ull);
                         const RefHit h = reference_walk(fap->r.sc.nodes, node_first, node_end, fap->r.sc.spheres, ray.o.x, ray.o.y, ray.o.z,
                                                         ray.d.x, ray.d.y, ray.d.z, ray.tm, ray_a);
                         best = h.best; closest = h.closest; /* an index into the scene's sphere table (HBM) */
                     }
+                    PROFF(0);
                 REGION("S:hitrecord");
                     if (best < 0) { /* camera.cuh:154-158 */
                         final_value = mk(bg_x, bg_y, bg_z);
@@ -598,7 +619,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                         DSphere sp;
                         if (need_ref) sp = fap->r.sc.spheres[best];
                         else { /* the winner's copy in its leaf record */
-                            const float4 *lp = (const float4 *)(leafrecs + (best >> 16)) + ((best & 0x8000) ? 2 : 0);
+                            const float4 *lp = leafrecs + (best >> 16) + ((best & 0x8000) ? 2 : 0);
                             const float4 s0 = lp[0], s1 = lp[1];
                             sp.cx = s0.x; sp.cy = s0.y; sp.cz = s0.z; sp.radius = s0.w; sp.vx = s1.x; sp.vy = s1.y; sp.vz = s1.z; sp.mat = __float_as_uint(s1.w);
                         }
@@ -607,6 +628,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                         const bool front_face = vdot(ray.d, outward) < 0;
                         const V3 normal = front_face ? outward : vneg(outward);
                         const int mtype = DREF_TYPE(sp.mat), midx = DREF_IDX(sp.mat);
+                        PROFF(1);
                         StackEntry e;
                         if (mtype == MORT_MAT_METAL) { /* materials.cuh:73-84 */
                 REGION("S:metal");
@@ -616,6 +638,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                             reflected = vadd(vunit(reflected), vscale(m.fuzz, random_unit_vector(rng)));
                             ray.o = p; ray.d = reflected;
                             e.kx = 1.0f * m.r; e.ky = 1.0f * m.g; e.kz = 1.0f * m.b; e.rp = 1.0f;
+                            PROFF(2);
                         } else if (mtype == MORT_MAT_DIELECTRIC) { /* materials.cuh:107-130 */
                 REGION("S:dielectric");
                             PROFB(1);
@@ -633,6 +656,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                             ray.o = p; ray.d = direction;
                             e.kx = 1.0f; e.ky = 1.0f; e.kz = 1.0f; e.rp = 1.0f;
                             ident_mask |= (1ull << iter);
+                            PROFF(3);
                         } else if (mtype == MORT_MAT_LAMBERTIAN || mtype == MORT_MAT_ISOTROPIC) {
                 REGION("S:lambertian");
                             PROFB(2);
@@ -658,6 +682,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                                     attenuation = mk(c.x, c.y, c.z);
                                 }
                             }
+                            PROFF(4);
                 REGION("S:lamb_scatter");
                             V3 dir;
                             float mat_pdf, scattering_pdf;
@@ -677,6 +702,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                             ray.o = p; ray.d = dir; ray.tm = ray_time0;
                             e.kx = scattering_pdf * attenuation.x; e.ky = scattering_pdf * attenuation.y; e.kz = scattering_pdf * attenuation.z;
                             e.rp = 1 / mat_pdf;
+                            PROFF(5);
                         } else { /* diffuse_light or unknown tag: no scatter (materials.cuh:151-163) */
                 REGION("S:light");
                             V3 emission = mk(0, 0, 0);
@@ -687,6 +713,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                             }
                             final_value = emission;
                             kind = K_FINISH;
+                            PROFF(6);
                         }
                 REGION("S:stackstore");
                         if (kind == K_SHADE) {
@@ -777,7 +804,7 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
                         const bool ordinary = own_inv_ok(orr.ix) && own_inv_ok(orr.iy) && own_inv_ok(orr.iz) && (mm < 1e30f);
                         closest = __builtin_inff();
                         best = -1;
-                        node = 0; sp = 0;
+                        node = 0; spa = ts_base;
                         flags = ordinary ? 0 : FL_REF;
                         segments++;
                         state = ordinary ? ST_T : ST_S;
@@ -798,6 +825,9 @@ __global__ void __launch_bounds__(BLOCK, (DRAIN && BLOCK < 768) ? (BLOCK + 255) 
     }
     if ((threadIdx.x & 63) == 0) {
 #ifdef MORT_PROFILE_STATES
+#ifdef MORT_PROFILE_FINE
+        for (int k = 0; k < 12; k++) atomicAdd(&counters_p[18 + k], proff[k]);
+#endif
         for (int k = 0; k < 6; k++) atomicAdd(&counters_p[4 + k], prof[k]);
         atomicAdd(&counters_p[30], prof_truns);
         for (int k = 0; k < 4; k++) atomicAdd(&counters_p[10 + k], profc[k]);

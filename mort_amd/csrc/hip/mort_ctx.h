@@ -49,7 +49,7 @@ struct mort_ctx {
     bool wave_ok = false; /* wavefront mode: one BVH over spheres as the whole world, hot blob fits LDS */
     /* BVH megakernel: its own LDS image (four-wide own tree, leaf records with their spheres, leaf boxes, material / texture tables) */
     void *d_fast = nullptr;
-    uint32_t f_leaves = 0, f_lambert = 0, f_metal = 0, f_diel = 0, f_dlight = 0, f_iso = 0,
+    uint32_t f_lambert = 0, f_metal = 0, f_diel = 0, f_dlight = 0, f_iso = 0,
              f_solid = 0, f_checker = 0, fast_bytes = 0, f_nodes4 = 0, f_leafrecs = 0;
     void *d_trav = nullptr; /* wf_trav's LDS image */
     uint32_t t_nodes2 = 0, t_leaves = 0, t_spheres = 0, trav_bytes = 0;

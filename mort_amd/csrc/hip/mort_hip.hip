@@ -267,11 +267,10 @@ extern "C" int mort_hip_upload_world(mort_ctx *c, const mort_world *w) {
     /* the LDS kernels handle: one BVH over spheres as the whole world */
     c->wave_ok = (o.items.size() == 1 && o.items[0].kind == ITEM_BVH && o.quads.empty());
     if (c->wave_ok && !o.own_nodes.empty() && !o.own_nodes4.empty()) {
-        /* two LDS images: the BVH megakernel's (four-wide nodes, leaf records with their spheres by value, leaf boxes, every small
+        /* two LDS images: the BVH megakernel's (four-wide nodes, leaf records with their spheres by value, every small
          * table) and the wavefront traversal kernel's (binary nodes, leaf nodes, spheres) */
         std::vector<unsigned char> fb, tb;
         c->f_nodes4 = (uint32_t)place(fb, o.own_nodes4); c->f_leafrecs = (uint32_t)place(fb, o.own_leafrecs);
-        c->f_leaves = (uint32_t)place(fb, o.own_leaves);
         c->f_lambert = (uint32_t)place(fb, o.lambert); c->f_metal = (uint32_t)place(fb, o.metal); c->f_diel = (uint32_t)place(fb, o.dielectric);
         c->f_dlight = (uint32_t)place(fb, o.dlight); c->f_iso = (uint32_t)place(fb, o.isotropic);
         c->f_solid = (uint32_t)place(fb, o.solid); c->f_checker = (uint32_t)place(fb, o.checker);
@@ -704,7 +703,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         std::memset(&fa, 0, sizeof fa);
         fa.r = a;
         fa.hot_src = (const unsigned char *)c->d_fast; fa.hot_bytes = c->fast_bytes;
-        fa.off_nodes4 = c->f_nodes4; fa.off_leaves = c->f_leaves; fa.off_leafrecs = c->f_leafrecs; fa.off_lambert = c->f_lambert; fa.off_metal = c->f_metal;
+        fa.off_nodes4 = c->f_nodes4; fa.off_leafrecs = c->f_leafrecs; fa.off_lambert = c->f_lambert; fa.off_metal = c->f_metal;
         fa.off_diel = c->f_diel; fa.off_dlight = c->f_dlight; fa.off_iso = c->f_iso; fa.off_solid = c->f_solid; fa.off_checker = c->f_checker;
         fa.node_first = 0; fa.node_count = c->sc.n_nodes; /* the reference's threaded nodes (HBM): fallback walk */
         fa.next_q = (unsigned int *)(c->d_counters + 2);
@@ -712,7 +711,11 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         if (substream) { fa.sub = cam->sqrt_spp; fa.vaccum = c->d_vaccum; fa.r.states = c->d_substates; }
         const long long lanes_wanted = (long long)tiles * 64;
         const double px_per_lane = (double)lanes_wanted / ((double)c->num_cus * 768.0);
-        /* workgroup size: the largest of {768, 512, 384, 256} that still gives every CU a workgroup
+        /* workgroup size.  Two pixels per lane or more: 1024 threads, compiled for 128 registers = 16 waves per CU.  A wave issues a
+         * dependent vector instruction every ~8 cycles and an independent one every ~5 (calibration), a SIMD can issue one
+         * every ~1.2: a fourth wave per SIMD is worth more than the 24 registers the 1024-thread build keeps in private memory, all of
+         * them touched in the shade step only (Scene 1: 103.7 ms against 111.9 ms with 768 threads at 153 registers).
+         * Otherwise the largest of {768, 512, 384, 256} that still gives every CU a workgroup
          * (a rank of an 8-way partition owns ~100 k pixels: 768-thread groups would leave half the CUs idle) */
         int FB = MORT_FAST_BLOCK;
         const char *fb_env = std::getenv("MORT_FAST_BLOCK_SIZE");
@@ -720,9 +723,11 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         else {
             const int cand[4] = {768, 512, 384, 256};
             FB = 256;
+            const bool wide_ok = lanes_wanted >= 2ll * 1024 * c->num_cus;
             /* about one pixel per lane or fewer: the frame is as long as its longest pixel chain, so take the drain kernels that are
              * compiled without spills (<= 512 threads; one rank of 4 at 1200x675: 81 ms vs 90 ms with 768) */
             for (int k = (px_per_lane < 1.5 && !substream) ? 1 : 0; k < 4; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; }
+            if (wide_ok) FB = 1024;
         }
         fa.drain_rounds = 0; /* DRAIN kernels follow the lane furthest behind (round 2); measured alternatives: 2 = rounds, 3 = thresholds as shares of the live lanes */
         { const char *dm = std::getenv("MORT_BVH_DRAIN"); if (dm) fa.drain_rounds = std::atoi(dm) == 2 ? 1 : std::atoi(dm) == 3 ? 3 : 0; }
@@ -731,13 +736,14 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         bool chain_bound = px_per_lane < 1.5 && !substream;
         { const char *cb = std::getenv("MORT_CHAIN_BOUND"); if (cb && !substream) chain_bound = cb[0] == '1'; }
         switch (FB) {
+        case 1024: kern = mega_bvh_kernel<1024, false, false>; kern_probe = mega_bvh_kernel<1024, true, false>; chain_bound = false; break; /* no drain variant: chain-bound partitions take <= 512 threads */
         case 768: kern = chain_bound ? mega_bvh_kernel<768, false, true> : mega_bvh_kernel<768, false, false>; kern_probe = mega_bvh_kernel<768, true, false>; break;
         case 512: kern = chain_bound ? mega_bvh_kernel<512, false, true> : mega_bvh_kernel<512, false, false>; kern_probe = mega_bvh_kernel<512, true, false>; break;
         case 384: kern = chain_bound ? mega_bvh_kernel<384, false, true> : mega_bvh_kernel<384, false, false>; kern_probe = mega_bvh_kernel<384, true, false>; break;
         default: FB = 256; kern = chain_bound ? mega_bvh_kernel<256, false, true> : mega_bvh_kernel<256, false, false>; kern_probe = mega_bvh_kernel<256, true, false>; break;
         }
         if (substream) /* <BLOCK, PROBE, DRAIN, SUB> */
-            kern = FB == 768 ? mega_bvh_kernel<768, false, false, true> : FB == 512 ? mega_bvh_kernel<512, false, false, true>
+            kern = FB == 1024 ? mega_bvh_kernel<1024, false, false, true> : FB == 768 ? mega_bvh_kernel<768, false, false, true> : FB == 512 ? mega_bvh_kernel<512, false, false, true>
                    : FB == 384 ? mega_bvh_kernel<384, false, false, true> : mega_bvh_kernel<256, false, false, true>;
         /* scheduling thresholds (mega_bvh.h).  Smaller batches do not help a chain-bound partition: measured on
          * one rank of 8, (32,24,16) 100 ms, (12,12,8) 126 ms, (2,2,2) 192 ms -- a lane waits through every step
@@ -753,7 +759,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         fa.off_tstack = tstack_off;
         uint32_t static_lds = 1024; /* the kernel's own __shared__ objects come out of the same 160 KB */
         { hipFuncAttributes fattr; if (hipFuncGetAttributes(&fattr, (const void *)kern) == hipSuccess) static_lds = (uint32_t)((fattr.sharedSizeBytes + 1023) & ~(size_t)1023); }
-        int groups_per_cu = 768 / FB; /* keep 12 waves per CU */
+        int groups_per_cu = FB >= 768 ? 1 : 768 / FB; /* keep 12 waves per CU */
         while (groups_per_cu > 1 && (long long)(stack_off + static_lds) * groups_per_cu > 160ll * 1024) groups_per_cu--;
         long long room = (160ll * 1024 - (long long)static_lds * groups_per_cu) / groups_per_cu - (long long)stack_off;
         if (room < 0) { c->last_error = "BVH image does not fit one CU's LDS"; return MORT_ERR_CAPACITY; }
@@ -950,6 +956,11 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             std::fprintf(stderr, "[cycles] T %.1f%% (%.0f/step)  L %.1f%% (%.0f/step)  S %.1f%% (%.0f/step)  sched %.1f%%  total wave-cycles %.3g\n",
                          100.0 * cnt[10] / tot, (double)cnt[10] / (double)cnt[4], 100.0 * cnt[11] / tot, (double)cnt[11] / (double)cnt[6],
                          100.0 * cnt[12] / tot, (double)cnt[12] / (double)cnt[8], 100.0 * cnt[13] / tot, tot);
+#ifdef MORT_PROFILE_FINE
+            std::fprintf(stderr, "[S shade parts, cycles/step] verify %.0f  hit record %.0f  metal %.0f  dielectric %.0f  lambert texture %.0f  lambert scatter %.0f  light %.0f  (rest of 'shade' below: stack store)\n",
+                         (double)cnt[18] / (double)cnt[8], (double)cnt[19] / (double)cnt[8], (double)cnt[20] / (double)cnt[8], (double)cnt[21] / (double)cnt[8],
+                         (double)cnt[22] / (double)cnt[8], (double)cnt[23] / (double)cnt[8], (double)cnt[24] / (double)cnt[8]);
+#else
             {
                 const char *bn[6] = {"metal", "dielectric", "lambertian", "finish", "get_ray", "unwind iteration"};
                 for (int k = 0; k < 6; k++)
@@ -957,6 +968,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
                                  100.0 * (double)cnt[18 + 2 * k] / (double)cnt[8], (double)cnt[18 + 2 * k] / (double)cnt[8],
                                  cnt[18 + 2 * k] ? (double)cnt[19 + 2 * k] / (double)cnt[18 + 2 * k] : 0.0);
             }
+#endif
             std::fprintf(stderr, "[S parts, cycles/step] shade %.0f  finish %.0f  newpix %.0f  newsample+setup %.0f\n", (double)cnt[14] / (double)cnt[8],
                          (double)cnt[15] / (double)cnt[8], (double)cnt[16] / (double)cnt[8], (double)cnt[17] / (double)cnt[8]);
         }
@@ -1037,16 +1049,16 @@ extern "C" int mort_hip_debug_own_tree(const mort_world *w, int *out) {
             out[7]++;
             const Rec r{{nd.xmin[k], nd.xmax[k], nd.ymin[k], nd.ymax[k], nd.zmin[k], nd.zmax[k], nd.e[k]}};
             if (ref & 0x8000u) {
-                const uint32_t l = ref & 0x7fffu;
-                if (l >= seen.size() || seen[l]++) { out[6]++; continue; }
+                const uint32_t l = (ref & 0x7fffu) / MORT_LEAF2_PIECES;
+                if ((ref & 0x7fffu) % MORT_LEAF2_PIECES || l >= seen.size() || seen[l]++) { out[6]++; continue; }
                 out[5]++;
                 if (std::memcmp(&r, &of_leaf[l], sizeof r) != 0) same = false;
             } else {
-                if (ref >= o.own_nodes4.size()) { out[6]++; continue; }
+                if (ref % MORT_NODE4_PIECES || ref / MORT_NODE4_PIECES >= o.own_nodes4.size()) { out[6]++; continue; }
                 bool found = false;
                 for (const Rec &b : of_inner) if (std::memcmp(&r, &b, sizeof r) == 0) { found = true; break; }
                 if (!found) same = false;
-                todo.push_back(ref);
+                todo.push_back(ref / MORT_NODE4_PIECES);
             }
         }
     }

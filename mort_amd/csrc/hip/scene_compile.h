@@ -332,54 +332,54 @@ struct Compiler {
         for (const DBvhNode &lf : leaves) {
             DLeaf2 r;
             std::memset(&r, 0, sizeof r);
-            r.pa = lf.prims & 0x7fffu; r.pb = (lf.prims >> 16) & 0x7fffu; r.n = r.pa == r.pb ? 1u : 2u;
-            if (r.pa >= out.spheres.size() || r.pb >= out.spheres.size()) { out.own_nodes.clear(); out.own_leaves.clear(); return; }
-            r.a = out.spheres[r.pa]; r.b = out.spheres[r.pb];
+            const uint32_t pa = lf.prims & 0x7fffu, pb = (lf.prims >> 16) & 0x7fffu;
+            if (pa >= out.spheres.size() || pb >= out.spheres.size()) { out.own_nodes.clear(); out.own_leaves.clear(); return; }
+            r.a = out.spheres[pa]; r.b = out.spheres[pb]; r.n = pa == pb ? 1u : 2u; r.prims = pa | (pb << 16);
+            r.xmin = lf.xmin; r.xmax = lf.xmax; r.ymin = lf.ymin; r.ymax = lf.ymax; r.zmin = lf.zmin; r.zmax = lf.zmax;
             out.own_leafrecs.push_back(r);
         }
         collapse_own_tree();
     }
-    /* ---- own_nodes four children wide.  Starting from a binary node's two children, the inner child with the largest box is replaced
-     * by its own two children until four slots are taken (or only leaves are left).  Slot order is irrelevant to the result: the walk
-     * orders the children it enters by entry distance, and equal hit distances are referred to the reference's walk whatever the order
-     * (mega_bvh.h).  Returns the most children a walk below this node can have pending: a step leaves at most (slots - 1) behind. ---- */
-    int collapse_emit(uint32_t b2, uint32_t me) {
-        struct Slot { uint32_t ref; float lo[3], hi[3], e; };
-        auto slot_of = [](const DNode2 &nd, int k) {
-            Slot s;
-            s.ref = k ? nd.child1 : nd.child0; s.e = k ? nd.e1 : nd.e0;
-            s.lo[0] = k ? nd.x1min : nd.x0min; s.hi[0] = k ? nd.x1max : nd.x0max;
-            s.lo[1] = k ? nd.y1min : nd.y0min; s.hi[1] = k ? nd.y1max : nd.y0max;
-            s.lo[2] = k ? nd.z1min : nd.z0min; s.hi[2] = k ? nd.z1max : nd.z0max;
-            return s;
-        };
-        std::vector<Slot> sl;
-        sl.push_back(slot_of(out.own_nodes[b2], 0)); sl.push_back(slot_of(out.own_nodes[b2], 1));
-        while (sl.size() < 4) {
-            int pick = -1; double pa = -1;
-            for (size_t i = 0; i < sl.size(); i++) {
-                if (sl[i].ref & 0x8000u) continue;
-                Box b; for (int k = 0; k < 3; k++) { b.lo[k] = sl[i].lo[k]; b.hi[k] = sl[i].hi[k]; }
-                const double a = box_area(b);
-                if (a > pa) { pa = a; pick = (int)i; }
-            }
-            if (pick < 0) break;
-            const DNode2 &nd = out.own_nodes[sl[pick].ref];
-            sl[pick] = slot_of(nd, 0);
-            sl.insert(sl.begin() + pick + 1, slot_of(nd, 1));
-        }
+    /* ---- own_nodes four children wide.  A four-wide node stands for a binary node n and holds a CUT of n's subtree of at most four
+     * members (inner binary nodes or leaves).  Which cut: the one that minimises the expected number of box steps of a walk under the
+     * surface-area measure, cost(n) = area(n) + the least total cost of a cut of at most four -- a small dynamic program over
+     * (node, members allowed), bottom up.  Member order is irrelevant to the result: the walk orders the children it enters by entry
+     * distance, and equal hit distances are referred to the reference's walk whatever the order (mega_bvh.h).  Boxes and margins
+     * are the binary tree's, bit for bit. ---- */
+    struct Slot4 { uint32_t ref; float lo[3], hi[3], e; };
+    static Slot4 slot_of(const DNode2 &nd, int k) {
+        Slot4 s;
+        s.ref = k ? nd.child1 : nd.child0; s.e = k ? nd.e1 : nd.e0;
+        s.lo[0] = k ? nd.x1min : nd.x0min; s.hi[0] = k ? nd.x1max : nd.x0max;
+        s.lo[1] = k ? nd.y1min : nd.y0min; s.hi[1] = k ? nd.y1max : nd.y0max;
+        s.lo[2] = k ? nd.z1min : nd.z0min; s.hi[2] = k ? nd.z1max : nd.z0max;
+        return s;
+    }
+    struct Cut4 { double t[5]; unsigned char left[5]; }; /* t[k]: least cost of a cut of at most k members; left[k]: members given to child 0 (0 = the node itself) */
+    void cut_expand(const std::vector<Cut4> &dp, const Slot4 &s, int k, std::vector<Slot4> &outv) const {
+        if ((s.ref & 0x8000u) || dp[s.ref].left[k] == 0) { outv.push_back(s); return; }
+        const int i = dp[s.ref].left[k];
+        cut_expand(dp, slot_of(out.own_nodes[s.ref], 0), i, outv);
+        cut_expand(dp, slot_of(out.own_nodes[s.ref], 1), k - i, outv);
+    }
+    /* returns the most children a walk below this node can have pending: a step leaves at most (members - 1) behind */
+    int collapse_emit(const std::vector<Cut4> &dp, uint32_t b2, uint32_t me) {
+        std::vector<Slot4> sl;
+        const int i0 = dp[b2].left[0]; /* [0]: the split of this node's OWN cut of four */
+        cut_expand(dp, slot_of(out.own_nodes[b2], 0), i0, sl);
+        cut_expand(dp, slot_of(out.own_nodes[b2], 1), 4 - i0, sl);
         int below = 0;
         DNode4 n4;
         std::memset(&n4, 0, sizeof n4);
         for (int k = 0; k < 4; k++) n4.child[k] = 0xffffu;
-        for (size_t i = 0; i < sl.size(); i++) {
+        for (size_t i = 0; i < sl.size() && i < 4; i++) {
             n4.xmin[i] = sl[i].lo[0]; n4.xmax[i] = sl[i].hi[0]; n4.ymin[i] = sl[i].lo[1]; n4.ymax[i] = sl[i].hi[1];
             n4.zmin[i] = sl[i].lo[2]; n4.zmax[i] = sl[i].hi[2]; n4.e[i] = sl[i].e;
-            if (sl[i].ref & 0x8000u) { n4.child[i] = sl[i].ref; continue; }
+            if (sl[i].ref & 0x8000u) { n4.child[i] = 0x8000u | ((sl[i].ref & 0x7fffu) * MORT_LEAF2_PIECES); continue; }
             const uint32_t ci = (uint32_t)out.own_nodes4.size();
             out.own_nodes4.push_back(DNode4{});
-            n4.child[i] = ci;
-            const int d = collapse_emit(sl[i].ref, ci);
+            n4.child[i] = ci * MORT_NODE4_PIECES;
+            const int d = collapse_emit(dp, sl[i].ref, ci);
             if (d > below) below = d;
         }
         out.own_nodes4[me] = n4;
@@ -387,10 +387,49 @@ struct Compiler {
     }
     void collapse_own_tree() {
         out.own_nodes4.clear(); out.own4_stack = 0;
-        if (out.own_nodes.empty()) return;
+        const size_t n2 = out.own_nodes.size();
+        if (n2 == 0) return;
+        /* area of every binary node's own box: kept in its parent's record (the root: the union of its children) */
+        std::vector<double> area(n2, 0.0);
+        {
+            const Slot4 a = slot_of(out.own_nodes[0], 0), b = slot_of(out.own_nodes[0], 1);
+            Box u; for (int k = 0; k < 3; k++) { u.lo[k] = std::fmin(a.lo[k], b.lo[k]); u.hi[k] = std::fmax(a.hi[k], b.hi[k]); }
+            area[0] = box_area(u);
+        }
+        for (size_t n = 0; n < n2; n++)
+            for (int k = 0; k < 2; k++) {
+                const Slot4 c = slot_of(out.own_nodes[n], k);
+                if (c.ref & 0x8000u) continue;
+                if (c.ref <= n || c.ref >= n2) return; /* children follow their parent (own_emit) */
+                Box b; for (int j = 0; j < 3; j++) { b.lo[j] = c.lo[j]; b.hi[j] = c.hi[j]; }
+                area[c.ref] = box_area(b);
+            }
+        std::vector<Cut4> dp(n2);
+        for (size_t n = n2; n-- > 0;) {
+            const DNode2 &nd = out.own_nodes[n];
+            auto T = [&](uint32_t ref, int k) { return (ref & 0x8000u) ? 0.0 : dp[ref].t[k]; };
+            Cut4 c;
+            /* cuts of this node's subtree into i + j = k members, neither side empty */
+            double best_k[5]; unsigned char arg_k[5];
+            for (int k = 2; k <= 4; k++) {
+                best_k[k] = 1e300; arg_k[k] = 1;
+                for (int i = 1; i < k; i++) {
+                    const double v = T(nd.child0, i) + T(nd.child1, k - i);
+                    if (v < best_k[k]) { best_k[k] = v; arg_k[k] = (unsigned char)i; }
+                }
+            }
+            const double own = area[n] + best_k[4];
+            c.left[0] = arg_k[4];
+            c.t[0] = own; c.t[1] = own; c.left[1] = 0;
+            for (int k = 2; k <= 4; k++) {
+                c.t[k] = c.t[k - 1]; c.left[k] = c.left[k - 1];
+                if (best_k[k] < c.t[k]) { c.t[k] = best_k[k]; c.left[k] = arg_k[k]; }
+            }
+            dp[n] = c;
+        }
         out.own_nodes4.push_back(DNode4{});
-        out.own4_stack = collapse_emit(0, 0);
-        if (out.own4_stack > MORT_OWN4_STACK || out.own_nodes4.size() > 0x7fff) out.own_nodes4.clear();
+        out.own4_stack = collapse_emit(dp, 0, 0);
+        if (out.own4_stack > MORT_OWN4_STACK || out.own_nodes4.size() * MORT_NODE4_PIECES > 0x7fff || out.own_leaves.size() * MORT_LEAF2_PIECES > 0x7fff) out.own_nodes4.clear();
     }
 
     /* ---- this build's UNIFIED tree (mega_gen.hip, wave_gen.hip).  A world without reference BVHs is a linear

@@ -6,8 +6,9 @@ graph), waves per SIMD that allocation allows, spilled registers, private (scrat
 --check (run by `make hip`) fails the build when
   * a kernel's register allocation cannot host the workgroup its launch bounds promise (VGPRs rounded up to 8, 512 per SIMD), or
   * one of the state-machine megakernels (mega_bvh_kernel, mega_gen_kernel) touches private memory beyond a callee frame or spills
-    a vector register: their state loops are built to run without scratch; the 1024-thread mega_gen variant, which
-    is compiled for 128 VGPRs to measure four waves per SIMD, is the one listed exception.
+    a vector register: their state loops are built to run without scratch.  The 1024-thread variants are compiled
+    for 128 VGPRs (four waves per SIMD): mega_bvh_kernel<1024> may keep at most 32 registers / 128 B in private memory (rarely
+    touched per-pixel values, read and written in the shade step only), mega_gen_kernel<1024> is a measurement build.
 """
 import os, re, subprocess, sys, tempfile, shutil
 LLVM = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
@@ -47,7 +48,8 @@ for r in sorted(rows, key=lambda r: r["name"]):
     if need > waves:
         bad.append(f"{r['name']}: {r['vgpr']} VGPRs allow {waves} waves per SIMD, a {r['wg']}-thread workgroup needs {need}")
     if ("mega_bvh_kernel" in r["name"] or "mega_gen_kernel" in r["name"]) and not r["name"].startswith("mega_gen_kernel<1024"):
-        if r["vspill"] or r["private"] > 128:
+        wide = r["name"].startswith("mega_bvh_kernel<1024")
+        if (r["vspill"] > (32 if wide else 0)) or r["private"] > 128:
             bad.append(f"{r['name']}: {r['vspill']} spilled VGPRs, {r['private']} B of private memory per lane (state loop must run without scratch)")
 if bad:
     print("\n".join("RESOURCE CHECK FAILED: " + b for b in bad), file=sys.stderr)
