@@ -286,7 +286,7 @@ def main():
         # copy reaches, and the cycles a SIMD needs per wave64 VALU instruction at 1, 3 and 8 resident waves
         calib = None
         if world_size == 1 and not args.no_calib:
-            cv = {w: ctx.calib_valu(w, 0)["cycles_per_valu_per_simd"] for w in (1, 3, 8)}
+            cv = {w: ctx.calib_valu(w, 0)["cycles_per_valu_per_simd"] for w in (1, 3, 4, 8)}
             calib = {"hbm_copy_GBs": ctx.calib_hbm_copy(1 << 30, 3), "valu_cycles_per_inst_per_simd": {str(w): v for w, v in cv.items()},
                      "note": "mort_hip_calib_valu (independent v_fma_f32, waves per SIMD -> cycles per instruction per SIMD) and "
                              "mort_hip_calib_hbm_copy (float4 copy of 1 GiB per buffer, read + write)"}

@@ -150,7 +150,6 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
     uint32_t best = GBEST_NONE; /* entry code of the closest hit so far */
     uint32_t node = 0;          /* T: tree node; L: leaf */
     int sp = 0, flags = 0;      /* pending far children; GFL_REF */
-    V3 final_value = mk(0, 0, 0);
     unsigned long long ident_mask = 0ull;
 
 #ifdef MORT_PROFILE_STATES
@@ -317,6 +316,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
             GPROF(3, nS);
             /* ---- shade / finish / next sample / next pixel, then start the next ray ---- */
             GPROFS0();
+            V3 final_value = mk(0, 0, 0); /* a path's result lives inside one shade step (mega_bvh.h); the degenerate launches enter with K_FINISH and zero */
             if (state == G_S) {
                 if (kind == K_SHADE) {
                     if (flags) { /* worlds without media come here directly */

@@ -825,12 +825,15 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         int FB = 768;
         { const char *fb_env = std::getenv("MORT_GEN_BLOCK_SIZE");
           if (fb_env && !substream) FB = std::atoi(fb_env);
-          else { /* the state loop needs 157 VGPRs and no scratch: 768 threads = 3 waves per SIMD when the frame has many pixels per lane (4096 x 4096:
-                  * 143 vs 181 ms with 512); with a handful of pixels per lane the frame ends with its longest pixel chains, whose rounds are faster
-                  * with two waves per SIMD (800 x 800: 359 vs 370 ms); fewer pixels than lanes: 256-thread groups so every CU has work */
+          else { /* many pixels per lane: 1024 threads compiled for 128 registers = four waves per SIMD, which pays for its spills as in the BVH
+                  * kernel (4096 x 4096 x 4: 126.6 ms, 768 threads at 160 registers 137.5 ms, 512 threads 181 ms; 1920 x 1080 x 49: 173 vs 175 ms).
+                  * With a handful of pixels per lane the frame ends with its longest pixel chains, whose rounds are faster with two waves per
+                  * SIMD and no spills (final scene 800 x 800 x 961: 3.07 s with 512 threads, 3.21 s with 1024); fewer pixels than lanes:
+                  * 256-thread groups so every CU has work */
                  const double ppl = (double)lanes_wanted / ((double)c->num_cus * 768.0);
-                 FB = ppl >= 8.0 ? 768 : (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
+                 FB = ppl >= 8.0 ? 1024 : (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
         if (FB != 1024 && FB != 768 && FB != 512 && FB != 256) FB = 256;
+        if (FB == 1024 && (size_t)c->gen_bytes + 16u + (size_t)MORT_OWN_STACK * 1024u * 2u + 2048u > 160u * 1024u) FB = 768; /* image + traversal stacks of 1024 threads must fit */
         if (substream && FB > 512) FB = 512; /* the non-parity launch is instantiated for 512- and 256-thread workgroups */
         /* swept on the final scene, 800x800x100 (scripts/th_sweep.py, 180 settings): 373 ms here vs 449 ms with the BVH kernel's (40,24,12) and m = 24 */
         fa.th_s = 28; fa.th_l = 20; fa.t_keep = 4; ga.th_m = 56;

@@ -80,7 +80,22 @@ def test_final_scene_800x800_1000spp(oracle, monkeypatch):
     _same(a, w)
 
 
-@pytest.mark.parametrize("block", ["768", "256"])
+def test_headline_scene1_1200x675_500spp(oracle, monkeypatch):
+    """BASELINE config 2 (the headline) at its stated size: the 1024-thread BVH megakernel the launch picks (128 registers, four waves per
+    SIMD, some per-pixel values in private memory) == the 768-thread build without private memory == a four-way partition (512-thread
+    drain kernels, one context per rank) == the wavefront pipeline, bit for bit."""
+    world, cam = host.build_scene(1, width=1200, spp=500)
+    assert (cam.image_width, cam.image_height, cam.bounce_limit) == (1200, 675, 20)
+    a = _render(world, cam, oracle, monkeypatch)
+    assert a["name"].startswith("mega_bvh_kernel<1024"), a["name"]
+    b = _render(world, cam, oracle, monkeypatch, env={"MORT_FAST_BLOCK_SIZE": "768"})
+    assert b["name"].startswith("mega_bvh_kernel<768"), b["name"]
+    _same(a, b)
+    _same(a, _render(world, cam, oracle, monkeypatch, nranks=4))
+    _same(a, _render(world, cam, oracle, monkeypatch, mode=hip.MODE_WAVE))
+
+
+@pytest.mark.parametrize("block", ["1024", "768", "256"])
 def test_final_scene_workgroup_shapes_fill_the_chip(oracle, monkeypatch, block):
     """Every workgroup shape of the unified-tree megakernel on a frame that gives every CU several workgroups and reaches the deep
     (HBM) levels of the bounce stack: 800x800 x 16 spp of the final scene, >= 830 workgroups; the default shape is the reference."""
