@@ -37,12 +37,15 @@
 
 /* ====================================================================== device */
 
-/* 3 waves per SIMD: without the bound the compiler takes 172 VGPRs, two over the limit for three */
+/* 4 waves per SIMD: 128 registers and 9 bounce-stack levels in LDS (36 KB per workgroup, four workgroups per CU).  Without a bound the
+ * compiler takes 172 registers (two waves); at three (148 registers, 12 levels) the Cornell box 800x800x1000 took 360 ms, at four 326 ms,
+ * Cornell smoke 52.9 -> 47.2 ms -- a wave issues a dependent vector instruction only every ~8 cycles, so the fourth
+ * wave outweighs the extra spills (this kernel keeps its deep stack levels in private memory either way) */
 #ifndef MORT_GENERIC_WAVES
-#define MORT_GENERIC_WAVES 3
+#define MORT_GENERIC_WAVES 4
 #endif
 #ifndef MORT_MEGA_LDS_LEVELS
-#define MORT_MEGA_LDS_LEVELS 12
+#define MORT_MEGA_LDS_LEVELS 9
 #endif
 extern "C" __global__ void __launch_bounds__(256, MORT_GENERIC_WAVES)
 mega_kernel(const RenderArgs a) {
@@ -55,7 +58,7 @@ mega_kernel(const RenderArgs a) {
     const bool active = (x < a.width) && (ly < a.local_rows);
     if (!active) return;
 
-    __shared__ float4 s_stack[MORT_MEGA_LDS_LEVELS * 256]; /* bounce-stack levels 0..11 of the block's 256 lanes: 48 KB, three blocks per CU */
+    __shared__ float4 s_stack[MORT_MEGA_LDS_LEVELS * 256]; /* the first bounce-stack levels of the block's 256 lanes: 36 KB, four blocks per CU */
     const PixelTotals t = render_pixel<false>(a, nullptr, x, ly, nullptr, s_stack + threadIdx.x, MORT_MEGA_LDS_LEVELS, 256); /* dev_pixel.h: the body the host loop runs too */
     atomicAdd(&a.counters[0], (unsigned long long)t.segments);
     atomicAdd(&a.counters[1], (unsigned long long)t.draws);
