@@ -77,6 +77,8 @@ struct FastArgs {
     int prio_tiles, prio_lanes;
     int drain_rounds;           /* DRAIN kernels, once the pool is empty: 1 = run in rounds (every live lane one segment per shade step), 0 = follow the lane furthest behind */
     int tile_key_sum;           /* 1 = order tiles by their segment sum (round 2), 0 = by their longest pixel */
+    int lane_cap;               /* lanes of a wave that take pixels (64 = all).  A partition with fewer pixels than the chip has lanes is bound by the latency of its
+                                 * waves' steps, not by issue slots: the same pixels on MORE waves with FEWER lanes each shorten every wave's chain of steps */
     unsigned long long *wave_log; /* profile builds (-DMORT_PROFILE_STATES) with MORT_WAVE_LINES=1: 16 words per wave of the launch, else null */
 };
 
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (DRAIN && BLOCK < 7
     const unsigned total_q = (unsigned)BU_I(L.tiles_total) * 64u;
 
     /* per-lane state */
-    int state = ST_S, kind = K_NEWPIX;
+    int state = ((int)(threadIdx.x & 63u) < BU_I(L.lane_cap)) ? ST_S : ST_DONE, kind = K_NEWPIX;
     int xy = 0, lofs = 0; /* x | y << 16 */
     Rng rng; rng.d = rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = 0; rng.draws = 0;
     V3 pixel_color = mk(0, 0, 0);

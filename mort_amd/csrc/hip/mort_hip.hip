@@ -732,6 +732,10 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             for (int k = (px_per_lane < 1.5 && !substream) ? 1 : 0; k < 4; k++) if (lanes_wanted >= (long long)cand[k] * c->num_cus) { FB = cand[k]; break; }
             if (wide_ok) FB = 1024;
         }
+        /* 1024 threads: image + traversal stacks + one bounce-stack level per lane must fit one CU's LDS, else the widest shape that does */
+        if (FB == 1024 && (size_t)((fa.hot_bytes + 15u) & ~15u) + (size_t)c->own4_stack * 1024u * 2u + 2048u + 1024u * 16u > 160u * 1024u) FB = 768;
+        fa.lane_cap = 64;
+        { const char *lc = std::getenv("MORT_LANE_CAP"); if (lc && std::atoi(lc) >= 1 && std::atoi(lc) <= 64) fa.lane_cap = std::atoi(lc); }
         fa.drain_rounds = 0; /* DRAIN kernels follow the lane furthest behind (round 2); measured alternatives: 2 = rounds, 3 = thresholds as shares of the live lanes */
         { const char *dm = std::getenv("MORT_BVH_DRAIN"); if (dm) fa.drain_rounds = std::atoi(dm) == 2 ? 1 : std::atoi(dm) == 3 ? 3 : 0; }
         void (*kern)(const FastArgs) = nullptr, (*kern_probe)(const FastArgs) = nullptr;
