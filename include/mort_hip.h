@@ -146,7 +146,7 @@ int mort_hip_comm_selftest(mort_ctx *ctx);
 /* ---- roofline calibration (measurement only; bench.py prints the results beside the render kernels' counters).
  * mort_hip_calib_valu: shader cycles one SIMD needs per wave64 VALU instruction with exactly `waves_per_simd` (1..8) waves
  * resident on every SIMD; kind 0 = independent v_fma_f32, 1 = one dependent v_fma_f32 chain, 2 = independent v_fma_f64,
- * 3 = three v_fma_f32 per scalar instruction.  mort_hip_calib_hbm_copy: GB/s (read + write) of a float4 copy of `bytes`
+ * 3 = three v_fma_f32 per scalar instruction, 4 = independent v_pk_fma_f32 (two fma per lane and instruction).  mort_hip_calib_hbm_copy: GB/s (read + write) of a float4 copy of `bytes`
  * per buffer (use > 256 MB, the Infinity Cache), best of `reps`. ---- */
 typedef struct mort_calib_valu {
     int waves_per_simd, kind;

@@ -50,6 +50,9 @@ __global__ void __launch_bounds__(256) calib_valu_kernel(int iters, float x, flo
             } else if (KIND == 2) { /* 8 independent v_fma_f64, twice */
 #pragma unroll
                 for (int k = 0; k < CALIB_CHAINS; k++) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[k & 7]) : "v"(xd), "v"(yd));
+            } else if (KIND == 4) { /* 8 independent v_pk_fma_f32 (two fp32 fma per lane and instruction), twice */
+#pragma unroll
+                for (int k = 0; k < CALIB_CHAINS; k++) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(d[k & 7]) : "v"(xd), "v"(yd));
             } else { /* 12 independent v_fma_f32 with 4 scalar instructions between them (the state machine's mix: one SALU per three VALU) */
 #pragma unroll
                 for (int k = 0; k < CALIB_CHAINS; k++) {
@@ -78,10 +81,10 @@ __global__ void __launch_bounds__(256) calib_valu_kernel(int iters, float x, flo
 }
 
 extern "C" int mort_hip_calib_valu(mort_ctx *c, int waves_per_simd, int kind, mort_calib_valu *res) {
-    if (!c || !res || waves_per_simd < 1 || waves_per_simd > 8 || kind < 0 || kind > 3) return MORT_ERR_INVALID;
+    if (!c || !res || waves_per_simd < 1 || waves_per_simd > 8 || kind < 0 || kind > 4) return MORT_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     void (*kern)(int, float, float, unsigned long long *) =
-        kind == 0 ? calib_valu_kernel<0> : kind == 1 ? calib_valu_kernel<1> : kind == 2 ? calib_valu_kernel<2> : calib_valu_kernel<3>;
+        kind == 0 ? calib_valu_kernel<0> : kind == 1 ? calib_valu_kernel<1> : kind == 2 ? calib_valu_kernel<2> : kind == 4 ? calib_valu_kernel<4> : calib_valu_kernel<3>;
     const int blocks = c->num_cus * waves_per_simd;
     /* exactly waves_per_simd blocks fit a CU's 160 KB (the hardware hands LDS out in granules: a request that is not a multiple of
      * 2 KB is rounded up, and one block fewer fits than the byte count says) */

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Roofline calibration on the GPU box (include/mort_hip.h mort_hip_calib_*): cycles per wave64 VALU instruction per SIMD at
-1..8 resident waves for four instruction mixes, and the HBM copy rate.  Prints one JSON object (kept under profiles/).
+1..8 resident waves for five instruction mixes, and the HBM copy rate.  Prints one JSON object (kept under profiles/).
 usage: calib.py [out.json]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mort_amd import hip
-KINDS = {0: "independent v_fma_f32", 1: "dependent v_fma_f32 chain", 2: "independent v_fma_f64", 3: "3 v_fma_f32 : 1 s_add_u32"}
+KINDS = {0: "independent v_fma_f32", 1: "dependent v_fma_f32 chain", 2: "independent v_fma_f64", 3: "3 v_fma_f32 : 1 s_add_u32", 4: "independent v_pk_fma_f32"}
 out = {"valu": [], "hbm_copy_GBs": None}
 with hip.Context(0) as ctx:
     for kind in KINDS:
