@@ -105,3 +105,32 @@ def test_four_wide_tree_is_the_binary_tree_regrouped(sid):
     assert slots >= 2.9 * n4                     # three of four slots in use on average (the lowest nodes hold two or three leaves)
     assert 3 <= stack4 <= 24
     assert same == 1
+
+
+def test_four_wide_tree_on_small_and_random_worlds():
+    """The same invariants on worlds the built-in scenes do not contain: a handful of spheres (coincident, concentric), every material kind,
+    and random sphere fields of 5..400 spheres -- every leaf reached exactly once, boxes and margins the binary tree's, the pending-children
+    bound within the kernel's LDS stack; worlds with fewer than two reference leaf nodes have no own tree at all (generic kernel)."""
+    import ctypes as C
+    import numpy as np
+    from mort_amd import hip
+    from tests.worlds import custom_bvh_world, BVH_WORLDS
+    fn = hip.lib().mort_hip_debug_own_tree
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    rng = np.random.default_rng(11)
+    worlds = dict(BVH_WORLDS)
+    for n in (5, 9, 17, 33, 100, 257, 400):
+        worlds[f"random{n}"] = [((float(rng.uniform(-8, 8)), float(rng.uniform(0, 2)), float(rng.uniform(-8, 8))), float(rng.uniform(0.05, 0.9)),
+                                 ("lamb", (.5, .5, .5))) for _ in range(n)]
+    for name, spheres in worlds.items():
+        w = custom_bvh_world(spheres)
+        out = (C.c_int * 9)()
+        assert fn(C.cast(w.ptr, C.c_void_p), out) == 0, name
+        n2, leaves, depth2, n4, stack4, reached, bad, slots, same = list(out)
+        if leaves < 2:
+            assert n2 == 0 and n4 == 0, name
+            continue
+        assert n2 == leaves - 1 and depth2 <= 15, (name, list(out))
+        assert 1 <= n4 <= max(1, n2 // 2 + 1) and reached == leaves and bad == 0 and same == 1, (name, list(out))
+        assert slots == n4 - 1 + leaves and 1 <= stack4 <= 24, (name, list(out))
