@@ -73,13 +73,15 @@ def test_state_machine_kernels_have_no_private_memory():
 @pytest.mark.gpu
 def test_roofline_calibration_kernels(gpu_ctx):
     """mort_hip_calib_valu / mort_hip_calib_hbm_copy (bench.py's roofline calibration): a SIMD cannot issue a wave64 VALU instruction faster than
-    the SIMD-32's two cycles, a lone wave is slower than a full SIMD, fp64 is slower than fp32, and the copy moves at a plausible HBM rate."""
+    the SIMD-32's two cycles, a lone wave is slower than a full SIMD, fp64 and packed fp32 are slower than fp32, and the copy moves at a plausible HBM rate."""
     one = gpu_ctx.calib_valu(1, 0)
     four = gpu_ctx.calib_valu(4, 0)
     f64 = gpu_ctx.calib_valu(4, 2)
+    pk = gpu_ctx.calib_valu(4, 4)
     assert one["simds_seen"] == four["simds_seen"] == 1024 and four["resident_waves_per_simd"] == 4
     assert 1.9 < four["cycles_per_valu_per_simd"] < 3.0 < one["cycles_per_valu_per_simd"] < 6.0
     assert f64["cycles_per_valu_per_simd"] > 1.5 * four["cycles_per_valu_per_simd"]
+    assert pk["cycles_per_valu_per_simd"] > 1.5 * four["cycles_per_valu_per_simd"]  # v_pk_fma_f32: two fma per lane at the issue cost of two instructions
     assert 1.0 < one["clock_ghz"] < 2.6
     assert 2000 < gpu_ctx.calib_hbm_copy(1 << 29, 2) < 8000
 
