@@ -736,7 +736,9 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         if (FB == 1024 && (size_t)((fa.hot_bytes + 15u) & ~15u) + (size_t)c->own4_stack * 1024u * 2u + 2048u + 1024u * 16u > 160u * 1024u) FB = 768;
         fa.lane_cap = 64;
         { const char *lc = std::getenv("MORT_LANE_CAP"); if (lc && std::atoi(lc) >= 1 && std::atoi(lc) <= 64) fa.lane_cap = std::atoi(lc); }
-        fa.drain_rounds = 0; /* DRAIN kernels follow the lane furthest behind (round 2); measured alternatives: 2 = rounds, 3 = thresholds as shares of the live lanes */
+        fa.drain_rounds = 3; /* batch thresholds as shares of the wave's LIVE lanes (they differ from fixed counts only once lanes have run out of pixels: the tail of a frame;
+                              * three runs each, one box: N = 1 100.1-100.5 vs 100.3-102.9 ms, a rank of 2 75.6-78.6 vs 77.6-82.2 ms, ranks of 4 / 8 unchanged); DRAIN kernels
+                              * also follow the lane furthest behind (round 2).  MORT_BVH_DRAIN: 0 / 1 = fixed counts, 2 = rounds, 3 = this */
         { const char *dm = std::getenv("MORT_BVH_DRAIN"); if (dm) fa.drain_rounds = std::atoi(dm) == 2 ? 1 : std::atoi(dm) == 3 ? 3 : 0; }
         void (*kern)(const FastArgs) = nullptr, (*kern_probe)(const FastArgs) = nullptr;
         /* chain-bound partition (about one pixel per lane or fewer): drain mode + spread fetches (mega_bvh.h) */

@@ -200,6 +200,7 @@ def test_wavefront_mode_rejects_unsupported_worlds(gpu_ctx):
     {"MORT_CHAIN_BOUND": "1", "MORT_SPREAD_SHIFT": "3"}, {"MORT_CHAIN_BOUND": "0", "MORT_SPREAD_SHIFT": "0"},
     {"MORT_NO_TILE_ORDER": "1"}, {"MORT_THRESHOLDS": "2,2,2"}, {"MORT_THRESHOLDS": "64,64,64"},
     {"MORT_FAST_BLOCK_SIZE": "256"}, {"MORT_FAST_BLOCK_SIZE": "512", "MORT_CHAIN_BOUND": "1"}, {"MORT_FAST_BLOCK_SIZE": "1024"},
+    {"MORT_BVH_DRAIN": "0"}, {"MORT_BVH_DRAIN": "2", "MORT_CHAIN_BOUND": "1"},
 ])
 def test_scheduling_choices_do_not_reach_the_pixels(gpu_ctx, oracle, monkeypatch, env):
     """Which lanes take which pixels, in which order, in which batch sizes and workgroup shapes (cost-ordered tiles,
