@@ -5,10 +5,12 @@
  * CDNA4 design (each point bit-identical to the reference's arithmetic):
  *
  *  - Scene in LDS.  The kernel's image of the scene (its own tree as four-child nodes, a record per reference leaf
- *    node with its one or two spheres by value, the leaf boxes, material and texture tables: 55 KB for Scene 1) is
+ *    node with its one or two spheres by value and the leaf's box, material and texture tables: 55 KB for Scene 1) is
  *    copied into LDS once per workgroup; a box step reads one node with eight independent ds_read_b128, a leaf step
- *    one record with five.  Node and record sizes are an ODD number of 16-byte pieces (144 B, 80 B): the lanes of a
+ *    one record with five.  Node and record sizes are an ODD number of 16-byte pieces (144 B, 112 B): the lanes of a
  *    wave read the same piece of different records, and only an odd stride spreads those over all LDS banks.
+ *    Frames with two pixels per lane or more run on 1024-thread workgroups compiled for 128 registers: four waves
+ *    per SIMD (DESIGN.md 4.1 h).
  *    The reference reads 4 SoA arrays + a 24-byte aabb from global memory per node (objects.cuh:728-731).
  *
  *  - Per-lane state machine, wave-level scheduling.  Each lane owns one pixel
