@@ -532,6 +532,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (DRAIN && BLOCK < 7
         PROFC(3);
 
                 REGION("T");
+        if (pick == ST_S) break; /* the shade step is the outer loop's body */
         if (pick == ST_T) {
             /* ---- own-tree steps: both child boxes of one node, near child next, far child pushed ---- */
             int keep;
@@ -588,7 +589,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (DRAIN && BLOCK < 7
                 }
             } while (keep >= t_keep);
             PROFC(0);
-        } else if (pick == ST_L) {
+        } else {
                 REGION("L");
             /* ---- leaf: sphere::hit on the one or two spheres of a reference leaf node (objects.cuh:60-77,690-692) ---- */
             PROF(1, nL);
@@ -620,7 +621,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (DRAIN && BLOCK < 7
                 } else { state = ST_S; kind = K_SHADE; }
             }
             PROFC(1);
-        } else break;
+        }
       }
       if (!running) break;
         {
