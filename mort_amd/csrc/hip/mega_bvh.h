@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (DRAIN && BLOCK < 7
         PROFC(3);
 
                 REGION("T");
-        if (pick == ST_S) break; /* the shade step is the outer loop's body */
+        if (pick != ST_T && pick != ST_L) break; /* ST_S: the shade step is the outer loop's body */
         if (pick == ST_T) {
             /* ---- own-tree steps: both child boxes of one node, near child next, far child pushed ---- */
             int keep;
@@ -589,7 +589,8 @@ __global__ void __launch_bounds__(BLOCK, BLOCK == 1024 ? 4 : (DRAIN && BLOCK < 7
                 }
             } while (keep >= t_keep);
             PROFC(0);
-        } else {
+        }
+        if (pick == ST_L) { /* not `else`: two simple diamonds, each merging a modified state with the unmodified one, leave hipcc nothing to copy at a common join */
                 REGION("L");
             /* ---- leaf: sphere::hit on the one or two spheres of a reference leaf node (objects.cuh:60-77,690-692) ---- */
             PROF(1, nL);

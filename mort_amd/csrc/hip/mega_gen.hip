@@ -216,6 +216,9 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
         }
         GPROFC(4);
 
+        if (pick != G_T && pick != G_L && pick != G_M) break; /* G_S: the shade step is the outer loop's body */
+        /* three sequential diamonds, not an if / else-if chain: each merges a modified search state with the unmodified one, so hipcc has nothing to
+         * copy at a common join (mega_bvh.h: seven register copies per scheduler pass otherwise) */
         if (pick == G_T) {
             /* ---- box steps: both child boxes of one node, near child next, far child pushed ---- */
             int keep;
@@ -253,7 +256,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 }
             } while (keep >= t_keep);
             GPROFC(0);
-        } else if (pick == G_L) {
+        }
+        if (pick == G_L) {
             GPROF(1, nL);
             /* ---- leaf: the own hit test of each primitive of the leaf, in its own frame
              *      (sphere::hit objects.cuh:60-77, quad::hit :190-215 under translate / rotate_y :268-278,334-366) ---- */
@@ -293,7 +297,8 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 } else { state = (has_media || flags) ? G_M : G_S; kind = K_SHADE; }
             }
             GPROFC(1);
-        } else if (pick == G_M) {
+        }
+        if (pick == G_M) {
             GPROF(2, nM);
             /* ---- after the solids: the scan itself for undecided rays, then the constant media in scan order
              *      (constant_medium::hit, objects.cuh:396-434; world.cuh:154-160) ---- */
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 state = G_S; kind = K_SHADE;
             }
             GPROFC(2);
-        } else break;
+        }
       }
       if (!running) break;
         {
