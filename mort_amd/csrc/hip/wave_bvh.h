@@ -213,7 +213,8 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
                 keep = __popcll(__ballot(state == W_T));
             } while (keep >= MORT_WF_T_KEEP);
             WPROFC(0);
-        } else if (pick == W_L) {
+        }
+        if (pick == W_L) { /* sequential ifs, not a chain: no register copies at a common join (mega_bvh.h) */
             WPROF(1, nL);
             if (state == W_L) { /* sphere::hit on the spheres of a reference leaf node (objects.cuh:60-77,690-692) */
                 const uint32_t leaf = leaves[node].prims;
@@ -237,7 +238,8 @@ __global__ void __launch_bounds__(BLOCK) wf_trav(const WfArgs w) {
                 } else state = W_F;
             }
             WPROFC(1);
-        } else {
+        }
+        if (pick == W_F) {
             WPROF(2, nF);
             /* wave-uniform control flow: every lane runs this block.  The refill comes first so that the
              * wait for the prefetched batch never covers the stores issued by this step's retire. */

@@ -201,7 +201,8 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs) {
                 keep = __popcll(__ballot(state == W_T));
             } while (keep >= t_keep);
             WGPROFC(0);
-        } else if (pick == W_L) {
+        }
+        if (pick == W_L) { /* sequential ifs, not a chain: no register copies at a common join (mega_bvh.h) */
             WGPROF(1, nL);
             uint32_t lpos = 0;
             int cnt = 0;
@@ -233,7 +234,8 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs) {
                 } else state = W_F;
             }
             WGPROFC(1);
-        } else {
+        }
+        if (pick == W_F) {
             WGPROF(2, nF);
             /* wave-uniform control flow: every lane runs this block */
             const bool inF = (state == W_F);
