@@ -358,7 +358,7 @@ DEV void wf_texture(const DScene &sc, const DLambert &m, V3 outward, V3 p, V3 &c
     color = texture_value(sc, tex, u, v, p);
 }
 
-extern "C" __global__ void __launch_bounds__(256) wf_shade(const WfArgs w) {
+extern "C" __global__ void __launch_bounds__(256, MORT_WF_SHADE_WAVES) wf_shade(const WfArgs w) {
     const RenderArgs &a = w.r;
     const DScene &sc = a.sc;
     const int par = w.parity;

@@ -6,6 +6,10 @@
 #ifndef MORT_WAVE_COMMON_H
 #define MORT_WAVE_COMMON_H
 
+
+#ifndef MORT_WF_SHADE_WAVES
+#define MORT_WF_SHADE_WAVES 4 /* waves per SIMD the two shade kernels (wf_shade, wf_shade_gen) are compiled for: measured 4 / 5 / 6 / 8, DESIGN.md 4.5 */
+#endif
 #include "dev_render.h"
 
 struct __attribute__((aligned(16))) WfRay { float ox, oy, oz, tm; float dx, dy, dz, time0; };

@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(BLOCK) wf_trav_gen(const WfGenArgs) {
 }
 
 /* ---- shading of one front ---- */
-__global__ void __launch_bounds__(256) wf_shade_gen(const WfGenArgs w) {
+__global__ void __launch_bounds__(256, MORT_WF_SHADE_WAVES) wf_shade_gen(const WfGenArgs w) {
     const GenArgs &ga = w.g;
     const RenderArgs &a = ga.f.r;
     const DScene &sc = a.sc;
