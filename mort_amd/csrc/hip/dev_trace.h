@@ -279,13 +279,13 @@ DEV bool world_hit(const DScene &sc, const Ray &r, Rng &rng, Best &best) {
     best.kind = HIT_NONE; best.t = 0; best.prim = 0; best.chain_first = 0; best.chain_count = 0;
     for (int i = 0; i < sc.n_items; i++) {
         const DItem it = sc.items[i];
-        if (it.kind == ITEM_BVH) {
-            run_bvh(sc, r, it.first, it.count, t_min, closest, best);
-        } else if (it.kind == ITEM_SPHERES) {
-            run_spheres(sc, r, it.first, it.count, it.chain_first, it.chain_count, t_min, closest, best);
-        } else if (it.kind == ITEM_QUADS) {
-            run_quads(sc, r, it.first, it.count, it.chain_first, it.chain_count, t_min, closest, best);
-        } else { /* constant_medium::hit, objects.cuh:396-434 */
+        /* sequential ifs on the (wave-uniform) item kind, not an if / else-if chain: each merges a modified (closest, best, stream) with the unmodified one,
+         * so hipcc updates the registers in place instead of copying them around a common join (mega_bvh.h) */
+        const int kind = it.kind;
+        if (kind == ITEM_BVH) run_bvh(sc, r, it.first, it.count, t_min, closest, best);
+        if (kind == ITEM_SPHERES) run_spheres(sc, r, it.first, it.count, it.chain_first, it.chain_count, t_min, closest, best);
+        if (kind == ITEM_QUADS) run_quads(sc, r, it.first, it.count, it.chain_first, it.chain_count, t_min, closest, best);
+        if (kind != ITEM_BVH && kind != ITEM_SPHERES && kind != ITEM_QUADS) { /* constant_medium::hit, objects.cuh:396-434 */
             const Ray rm = apply_chain(sc, r, it.chain_first, it.chain_count);
             float t1, t2;
             if (!boundary_t(sc, r, it.first, it.count, -__builtin_inff(), __builtin_inff(), t1)) continue;
