@@ -79,6 +79,11 @@ struct FastArgs {
     int prio_tiles, prio_lanes;
     int drain_rounds;           /* DRAIN kernels, once the pool is empty: 1 = run in rounds (every live lane one segment per shade step), 0 = follow the lane furthest behind */
     int tile_key_sum;           /* 1 = order tiles by their segment sum (round 2), 0 = by their longest pixel */
+    /* heavy waves (mega_gen.hip; measured there): of every heavy_mod consecutive waves the first heavy_num take pixels with heavy_cap lanes only and take them from
+     * the HEAD of the cost order (the first *prio_dev tiles: the frame's longest pixel chains) while it lasts; the other waves start at the tail.  A round of a wave
+     * costs less the fewer and the more alike its lanes are (final scene, tail waves: 64 lanes 60 us, 8 lanes 40 us, 4 lanes 31 us per round) */
+    const unsigned *prio_dev;   /* device word: tiles in the head (tile_sort.hip heavy_count_kernel), or null */
+    int heavy_mod, heavy_num, heavy_cap;
     int lane_cap;               /* lanes of a wave that take pixels (64 = all).  A partition with fewer pixels than the chip has lanes is bound by the latency of its
                                  * waves' steps, not by issue slots: the same pixels on MORE waves with FEWER lanes each shorten every wave's chain of steps */
     unsigned long long *wave_log; /* profile builds (-DMORT_PROFILE_STATES) with MORT_WAVE_LINES=1: 16 words per wave of the launch, else null */
@@ -320,7 +325,7 @@ __device__ __attribute__((noinline)) void pixel_write(const FastArgs *fap, float
 struct PixelFetch { int got; /* 0, or 1 + the stratum row (SUB) */ int xy /* x | y << 16 | priority pixel << 31 */, lofs; uint32_t d, v0, v1, v2, v3, v4; };
 /* one atomicAdd per wave per refill; the lanes that call this together take consecutive slots */
 template <bool SUB = false>
-__device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap, unsigned total_q) {
+__device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap, unsigned total_q, int role = -1, unsigned head_tiles = 0u) {
     const FastArgs &fa = *fap;
     const RenderArgs &a = fa.r;
     PixelFetch pf; pf.got = 0; pf.xy = 0; pf.lofs = 0; pf.d = pf.v0 = pf.v1 = pf.v2 = pf.v3 = pf.v4 = 0;
@@ -332,15 +337,37 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
         int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));
         unsigned q = 0;
         bool from_a = false;
-        const unsigned total_a = SUB ? 0u : (unsigned)fa.prio_tiles * 64u;
-        if (total_a) { /* the head of the cost order: at most prio_lanes pixels of it per fetch */
+        const unsigned total_a = SUB ? 0u : (role >= 0 ? head_tiles * 64u : (unsigned)fa.prio_tiles * 64u);
+        bool by_role = false;
+        if (role >= 0 && total_a) { /* heavy waves (role 1) take the head of the cost order first, the others (role 0) the rest first; either takes what is left of the other part */
+            by_role = true;
+            const bool head_first = role == 1;
+            unsigned b1 = 0;
+            if (rank == 0) b1 = atomicAdd(head_first ? fa.next_q + 1 : fa.next_q, (unsigned)cnt);
+            b1 = __shfl(b1, __ffsll((long long)need) - 1);
+            const unsigned q1 = b1 + (unsigned)rank;
+            const bool got1 = head_first ? (q1 < total_a) : (q1 < total_q - total_a);
+            if (got1) { q = head_first ? q1 : total_a + q1; from_a = head_first; }
+            else {
+                const unsigned long long need2 = __ballot(1);
+                const int cnt2 = __popcll(need2);
+                const int rank2 = __builtin_amdgcn_mbcnt_hi((unsigned)(need2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need2, 0));
+                unsigned b2 = 0;
+                if (rank2 == 0) b2 = atomicAdd(head_first ? fa.next_q : fa.next_q + 1, (unsigned)cnt2);
+                b2 = __shfl(b2, __ffsll((long long)need2) - 1);
+                const unsigned q2 = b2 + (unsigned)rank2;
+                const bool got2 = head_first ? (q2 < total_q - total_a) : (q2 < total_a);
+                if (!got2) break; /* both parts are empty */
+                q = head_first ? total_a + q2 : q2; from_a = !head_first;
+            }
+        } else if (total_a) { /* the head of the cost order: at most prio_lanes pixels of it per fetch */
             const int ka = cnt < fa.prio_lanes ? cnt : fa.prio_lanes;
             unsigned base_a = 0;
             if (rank == 0) base_a = atomicAdd(fa.next_q + 1, (unsigned)ka);
             base_a = __shfl(base_a, __ffsll((long long)need) - 1);
             if (rank < ka && base_a + (unsigned)rank < total_a) { q = base_a + (unsigned)rank; from_a = true; }
         }
-        if (!from_a) {
+        if (!from_a && !by_role) {
             need = __ballot(1);
             cnt = __popcll(need);
             rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0));

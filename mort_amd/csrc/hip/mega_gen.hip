@@ -137,7 +137,17 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
     const size_t deep_stride = (size_t)gridDim.x * BLOCK;
 
     /* per-lane state */
-    int state = G_S, kind = K_NEWPIX;
+    /* heavy waves (FastArgs.heavy_*): a few lanes per wave on the head of the cost order */
+    unsigned head_tiles = 0u;
+    int role = -1;
+    if (!SUB && uni_i(L.f.heavy_mod) > 0 && uni_p(L.f.prio_dev) != nullptr) {
+        head_tiles = uni_u(*uni_p(L.f.prio_dev));
+        const int wave_global = (int)(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6));
+        role = uni_i((wave_global % uni_i(L.f.heavy_mod)) < uni_i(L.f.heavy_num) ? 1 : 0); /* wave-uniform: into an SGPR */
+        if (head_tiles == 0u) role = -1;
+    }
+    const int my_cap = role == 1 ? uni_i(L.f.heavy_cap) : uni_i(L.f.lane_cap);
+    int state = ((int)(threadIdx.x & 63u) < my_cap) ? G_S : G_DONE, kind = K_NEWPIX; /* FastArgs.lane_cap: 64 = every lane takes pixels */
     int xy = 0, lofs = 0;
     Rng rng; rng.d = rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = 0; rng.draws = 0;
     V3 pixel_color = mk(0, 0, 0);
@@ -422,7 +432,7 @@ __global__ void __launch_bounds__(BLOCK, (BLOCK == 1024 ? 4 : BLOCK == 512 ? MOR
                 }
                 GPROFS(1);
                 if (kind == K_NEWPIX) {
-                    const PixelFetch pf = pixel_fetch<SUB>(&gap->f, total_q);
+                    const PixelFetch pf = pixel_fetch<SUB>(&gap->f, total_q, role, head_tiles);
                     if (!pf.got) { state = G_DONE; xy = 0; }
                     else {
                         xy = pf.xy; lofs = pf.lofs;

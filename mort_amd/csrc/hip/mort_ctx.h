@@ -57,6 +57,7 @@ struct mort_ctx {
     bool fast_ok = false;
     /* unified-tree megakernel (mega_gen.hip): its LDS image and launch constants */
     void *d_gen = nullptr;
+    unsigned *d_prio_count = nullptr; int heavy_percent = 50; /* heavy waves: device word with the number of head tiles; its threshold */
     uint32_t gen_bytes = 0;
     GenArgs gen{};
     bool gen_ok = false;

@@ -216,7 +216,7 @@ extern "C" void mort_hip_shutdown(mort_ctx *c) {
     quiesce(c);
     mort_hip_comm_destroy(c);
     hipFree(c->d_tile_keys); hipFree(c->d_tile_iota); hipFree(c->d_sort_tmp);
-    hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_trav); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
+    hipFree(c->d_prio_count); hipFree(c->d_scene); hipFree(c->d_fast); hipFree(c->d_trav); hipFree(c->d_gen); hipFree(c->d_states); hipFree(c->d_seqmats);
     hipFree(c->d_substates); hipFree(c->d_vaccum);
     hipFree(c->d_rgba); hipFree(c->d_accum); hipFree(c->d_segpx); hipFree(c->d_counters); hipFree(c->d_wf);
     hipFree(c->d_tile_cost); hipFree(c->d_tile_order); hipFree(c->d_probe_states); hipFree(c->d_deep); hipFree(c->d_wave_log);
@@ -517,6 +517,10 @@ static int prepare_tile_order(mort_ctx *c, const mort_camera *cam, const RenderA
         c->tile_cap = (size_t)tiles;
         c->cost_key = 0;
     }
+    if (fa.heavy_mod > 0 && !c->d_prio_count) {
+        HIPCHK(c, hipMalloc((void **)&c->d_prio_count, 16 + 96 * sizeof(unsigned long long)));
+        HIPCHK(c, hipMemsetAsync(c->d_prio_count, 0, 16 + 96 * sizeof(unsigned long long), s));
+    }
     /* the costs belong to one (world, image geometry, partition, view): FNV-1a over all of it */
     unsigned long long key = 1469598103934665603ull;
     auto mix = [&key](const void *p, size_t n) { const unsigned char *b = (const unsigned char *)p; for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ull; } };
@@ -539,11 +543,20 @@ static int prepare_tile_order(mort_ctx *c, const mort_camera *cam, const RenderA
         pa.tile_order = nullptr; pa.tile_cost = c->d_tile_cost;
         { const char *tk = std::getenv("MORT_TILE_KEY"); pa.tile_key_sum = (tk && std::strcmp(tk, "sum") == 0) ? 1 : 0; }
         HIPCHK(c, launch_probe(pa));
+        if (c->d_prio_count) HIPCHK(c, hipMemcpyAsync(c->d_prio_count + 4, c->d_counters, 96 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s)); /* the probe's counters (its segment total), beside its tile costs */
         HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 96 * sizeof(unsigned long long), s)); /* probe totals and work cursor */
         c->cost_key = key;
     }
     /* order = argsort(cost, descending, equal costs by index), on the device and on this stream */
     HIPCHK(c, mort_tile_sort_desc(c->d_tile_cost, c->d_tile_keys, c->d_tile_iota, c->d_tile_order, c->d_sort_tmp, c->sort_tmp_bytes, tiles, s));
+    /* the head of the order: tiles whose longest pixel reaches heavy_percent % of the frame's longest (unified-tree kernel's heavy waves) */
+    fa.prio_dev = nullptr;
+    if (fa.heavy_mod > 0) {
+        /* d_prio_count: [0] the head's size for this launch (u32); from byte 16: the 96 counters of the frame (or probe) the tile costs come from */
+        HIPCHK(c, mort_tile_heavy_count(c->d_tile_keys, tiles, (unsigned)c->heavy_percent, (unsigned)(tiles / 2 > 0 ? tiles / 2 : 1),
+                                        (const unsigned long long *)(c->d_prio_count + 4), (unsigned long long)grid * (unsigned long long)FB, c->d_prio_count, s));
+        fa.prio_dev = c->d_prio_count;
+    }
     HIPCHK(c, hipMemsetAsync(c->d_tile_cost, 0, (size_t)tiles * sizeof(unsigned), s));
     fa.tile_order = c->d_tile_order; fa.tile_cost = c->d_tile_cost;
     { const char *tk = std::getenv("MORT_TILE_KEY"); fa.tile_key_sum = (tk && std::strcmp(tk, "sum") == 0) ? 1 : 0; }
@@ -832,6 +845,7 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
         if (substream) { fa.sub = cam->sqrt_spp; fa.vaccum = c->d_vaccum; fa.r.states = c->d_substates; }
         const long long lanes_wanted = (long long)tiles * 64;
         int FB = 768;
+        bool heavy_default = false;
         { const char *fb_env = std::getenv("MORT_GEN_BLOCK_SIZE");
           if (fb_env && !substream) FB = std::atoi(fb_env);
           else { /* many pixels per lane: 1024 threads compiled for 128 registers = four waves per SIMD, which pays for its spills as in the BVH
@@ -840,12 +854,24 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
                   * SIMD and no spills (final scene 800 x 800 x 961: 3.07 s with 512 threads, 3.21 s with 1024); fewer pixels than lanes:
                   * 256-thread groups so every CU has work */
                  const double ppl = (double)lanes_wanted / ((double)c->num_cus * 768.0);
-                 FB = ppl >= 8.0 ? 1024 : (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256; } }
+                 FB = ppl >= 8.0 ? 1024 : (lanes_wanted >= 512ll * c->num_cus) ? 512 : 256;
+                 /* fewer pixels per lane: the frame may be bound by its longest pixel chains, and then HEAVY WAVES pay (below): 1024 threads, the launch decides on the device */
+                 if (ppl < 8.0 && lanes_wanted >= 32ll * 1024 && !std::getenv("MORT_GEN_NO_HEAVY")) { FB = 1024; heavy_default = true; } } }
         if (FB != 1024 && FB != 768 && FB != 512 && FB != 256) FB = 256;
         if (FB == 1024 && (size_t)c->gen_bytes + 16u + (size_t)MORT_OWN_STACK * 1024u * 2u + 2048u > 160u * 1024u) FB = 768; /* image + traversal stacks of 1024 threads must fit */
         if (substream && FB > 512) FB = 512; /* the non-parity launch is instantiated for 512- and 256-thread workgroups */
         /* swept on the final scene, 800x800x100 (scripts/th_sweep.py, 180 settings): 373 ms here vs 449 ms with the BVH kernel's (40,24,12) and m = 24 */
         fa.th_s = 28; fa.th_l = 20; fa.t_keep = 4; ga.th_m = 56;
+        fa.lane_cap = 64;
+        { const char *lc = std::getenv("MORT_LANE_CAP"); if (lc && std::atoi(lc) >= 1 && std::atoi(lc) <= 64) fa.lane_cap = std::atoi(lc); }
+        /* heavy waves (mega_bvh.h FastArgs.heavy_*): "mod,num,cap,percent" */
+        fa.heavy_mod = 0; fa.heavy_num = 0; fa.heavy_cap = 64; c->heavy_percent = 50;
+        /* default where the frame has fewer than 8 pixels per lane: two waves of three take 12 lanes each from the tiles whose longest pixel reaches half of the frame's
+         * longest -- IF the device finds the frame chain-bound (tile_sort.hip heavy_count_kernel); final scene 800x800x961: 3.04 -> 2.55 s, x100: 318 -> 270 ms */
+        if (heavy_default && FB == 1024 && !substream) { fa.heavy_mod = 3; fa.heavy_num = 2; fa.heavy_cap = 12; }
+        { const char *hv = std::getenv("MORT_GEN_HEAVY"); int m_ = 0, n_ = 0, k_ = 0, p_ = 0;
+          if (hv && !substream && std::sscanf(hv, "%d,%d,%d,%d", &m_, &n_, &k_, &p_) == 4 && m_ >= 1 && n_ >= 1 && n_ <= m_ && k_ >= 1 && k_ <= 64 && p_ >= 1 && p_ <= 100) {
+              fa.heavy_mod = m_; fa.heavy_num = n_; fa.heavy_cap = k_; c->heavy_percent = p_; } }
         ga.drain_mode = 3; /* thresholds as shares of the live lanes; measured alternatives: 0 = fixed counts, 1 = follow one lane, 2 = rounds */
         { const char *dm = std::getenv("MORT_GEN_DRAIN"); if (dm) ga.drain_mode = std::atoi(dm); }
         { const char *th = std::getenv("MORT_GEN_THRESHOLDS"); /* "s,l,k,m" */
@@ -910,6 +936,14 @@ static int render_device_impl(mort_ctx *c, const mort_camera *cam, int mode, voi
             }
         }
         HIPCHK(c, mort_gen_launch(ga, FB, grid, lds_bytes, s));
+        if (fa.heavy_mod > 0 && c->d_prio_count && std::getenv("MORT_GEN_HEAVY_DEBUG")) { /* diagnostic: what the device decided for this launch */
+            unsigned h[4] = {0, 0, 0, 0};
+            HIPCHK(c, hipStreamSynchronize(s));
+            HIPCHK(c, hipMemcpy(h, c->d_prio_count, 16, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[heavy] head tiles %u of %d, lanes %d\n", h[0], tiles, grid * FB);
+        }
+        if (fa.heavy_mod > 0 && c->d_prio_count) /* this frame's segment total, beside the tile costs it leaves for the next frame's order */
+            HIPCHK(c, hipMemcpyAsync(c->d_prio_count + 4, c->d_counters, 96 * sizeof(unsigned long long), hipMemcpyDeviceToDevice, s));
         if (substream) {
             const int npx = W * a.local_rows;
             hipLaunchKernelGGL(substream_resolve_kernel, dim3((npx + 255) / 256), dim3(256), 0, s, (const float *)c->d_vaccum, W, a.local_rows, cam->sqrt_spp,
