@@ -106,6 +106,34 @@ def test_final_scene_workgroup_shapes_fill_the_chip(oracle, monkeypatch, block):
     _same(a, b)
 
 
+@pytest.mark.parametrize("heavy", ["3,2,12,50", "1,1,4,100", "4,1,8,75", "2,1,1,30"])
+def test_final_scene_heavy_waves_do_not_reach_the_pixels(oracle, monkeypatch, heavy):
+    """Heavy waves (mega_bvh.h FastArgs.heavy_*: some waves take a few lanes' worth of pixels from the head of the cost order, the others start
+    behind it; which tiles form the head is decided on the device) are scheduling only: the final scene 800x800 x 16 spp with them forced in
+    four shapes -- and a second frame, whose head comes from the first frame's costs instead of the probe's -- equals the launch without them."""
+    world, cam = host.build_scene(8, width=800, spp=16)
+    a = _render(world, cam, oracle, monkeypatch, env={"MORT_GEN_NO_HEAVY": "1"})
+    b = _render(world, cam, oracle, monkeypatch, env={"MORT_GEN_HEAVY": heavy, "MORT_GEN_BLOCK_SIZE": "1024"})
+    assert b["name"].startswith("mega_gen_kernel<1024"), b["name"]
+    _same(a, b)
+    W, H = cam.image_width, cam.image_height
+    for k, v in {"MORT_GEN_HEAVY": heavy, "MORT_GEN_BLOCK_SIZE": "1024"}.items():
+        monkeypatch.setenv(k, v)
+    with hip.Context(0) as ctx:  # two frames on one context: the streams continue, the second frame's order and head come from the first one's costs
+        ctx.upload_world(world); ctx.rng_seed(S.DEFAULT_SEED, W, H)
+        f1 = ctx.render(cam, want_accum=False, want_segments=True)
+        f2 = ctx.render(cam, want_accum=False, want_segments=True)
+    monkeypatch.delenv("MORT_GEN_HEAVY"); monkeypatch.delenv("MORT_GEN_BLOCK_SIZE")
+    monkeypatch.setenv("MORT_GEN_NO_HEAVY", "1")
+    with hip.Context(0) as ctx:
+        ctx.upload_world(world); ctx.rng_seed(S.DEFAULT_SEED, W, H)
+        g1 = ctx.render(cam, want_accum=False, want_segments=True)
+        g2 = ctx.render(cam, want_accum=False, want_segments=True)
+    monkeypatch.delenv("MORT_GEN_NO_HEAVY")
+    assert (f1["rgba"] == g1["rgba"]).all() and (f2["rgba"] == g2["rgba"]).all()
+    assert (f2["segments_px"] == g2["segments_px"]).all() and f2["stats"]["segments"] == g2["stats"]["segments"]
+
+
 def test_config4_geometry_depth40(oracle, monkeypatch):
     """BASELINE config 4's frame (final scene 1920x1080, depth 40) at 4 spp: megakernel == two-way partition == wavefront pipeline."""
     world, cam = host.build_scene(8, width=1920, spp=4, aspect=16.0 / 9.0)
