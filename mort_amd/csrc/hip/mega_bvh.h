@@ -385,7 +385,7 @@ __device__ __attribute__((noinline)) PixelFetch pixel_fetch(const FastArgs *fap,
          * group u -> tile rank g*G + (w + u*S) mod G, pixel group u of that tile: a rotation per u,
          * hence a bijection between slots and pixels. */
         int tslot = (int)(q >> 6), within = (int)(q & 63u);
-        if (fa.gen_tiles > 0 && !from_a) {
+        if (fa.gen_tiles > 0 && !from_a && !by_role) { /* (heavy-wave launches hand out whole tiles in order) */
             const int g = tslot / fa.gen_tiles, w = tslot - g * fa.gen_tiles;
             const int left = fa.tiles_total - g * fa.gen_tiles;
             const int G = left < fa.gen_tiles ? left : fa.gen_tiles;
